@@ -1,0 +1,76 @@
+"""ctypes binding of libdeepgrp_hip.so (the C ABI declared in include/deepgrp_hip.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdeepgrp_hip.so")
+
+i64, i32, vp, cint = C.c_int64, C.c_int32, C.c_void_p, C.c_int
+
+
+class DgrpError(RuntimeError):
+    """A libdeepgrp_hip call failed (message from dgrp_last_error())."""
+
+
+class Segment(C.Structure):
+    """struct dgrp_segment"""
+    _fields_ = [("start", C.c_int64), ("end", C.c_int64), ("label", C.c_int32), ("contig", C.c_int32)]
+
+
+_SIGNATURES = {
+    "dgrp_abi_version": (cint, []),
+    "dgrp_last_error": (C.c_char_p, []),
+    "dgrp_device_info": (cint, [C.c_char_p, C.c_size_t, C.POINTER(cint), C.POINTER(i64)]),
+    "dgrp_strip_n": (cint, [vp, i64, C.POINTER(i64), C.POINTER(i64)]),
+    "dgrp_encode": (cint, [vp, i64, vp, vp]),
+    "dgrp_onehot": (cint, [vp, i64, vp, vp]),
+    "dgrp_window_count": (i64, [i64, i64, i64]),
+    "dgrp_windows_onehot": (cint, [vp, i64, i64, i64, i64, i64, cint, vp, vp]),
+    "dgrp_model_create": (cint, [C.POINTER(vp), cint, cint, cint, cint, vp, vp, vp, vp, vp, vp]),
+    "dgrp_model_destroy": (cint, [vp]),
+    "dgrp_model_dims": (cint, [vp, C.POINTER(cint), C.POINTER(cint), C.POINTER(cint), C.POINTER(cint)]),
+    "dgrp_forward_workspace_bytes": (i64, [vp, i64]),
+    "dgrp_forward_windows": (cint, [vp, vp, i64, i64, i64, i64, vp, vp, i64, vp]),
+    "dgrp_forward_merge": (cint, [vp, vp, i64, i64, i64, i64, i64, vp, vp, i64, vp]),
+    "dgrp_get_max": (cint, [vp, i64, vp, i64, i64, i64, i64, vp]),
+    "dgrp_scores": (cint, [vp, i64, cint, vp, vp, vp]),
+    "dgrp_softmax_labels": (cint, [vp, i64, cint, vp, vp, vp, i64, vp]),
+    "dgrp_mss_workspace_bytes": (i64, [i64]),
+    "dgrp_mss_labels": (cint, [vp, vp, i64, cint, cint, cint, vp, vp, vp, i64, vp]),
+    "dgrp_mss_segments_host": (cint, [vp, i64, vp, i64, C.POINTER(i64)]),
+    "dgrp_segments_workspace_bytes": (i64, [i64]),
+    "dgrp_segments": (cint, [vp, i64, i64, i32, vp, i64, vp, vp, i64, vp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """The loaded library; raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C deepgrp_amd/csrc` (hipcc, gfx950) "
+                "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        if L.dgrp_abi_version() != 1:
+            raise ImportError("libdeepgrp_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().dgrp_last_error().decode("utf-8", "replace")
+        raise DgrpError(f"{what or 'libdeepgrp_hip'} failed (code {rc}): {msg}")
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)

@@ -1,0 +1,241 @@
+// C-ABI glue of libdeepgrp_hip.so: error channel, device query, model packing/upload and the
+// forward entry points that sequence the GRU and attention kernels.
+#include "dgrp_model.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void dgrp_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+DGRP_EXPORT int dgrp_abi_version(void) { return DGRP_ABI_VERSION; }
+DGRP_EXPORT const char *dgrp_last_error(void) { return g_err; }
+
+DGRP_EXPORT int dgrp_device_info(char *name, size_t name_cap, int *cu_count, int64_t *hbm_bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { dgrp_set_error("no HIP device: %s", hipGetErrorString(e)); return DGRP_ENODEV; }
+    hipDeviceProp_t prop;
+    DGRP_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        dgrp_set_error("device %d is %s; this library is built for gfx950 only", dev, prop.gcnArchName);
+        return DGRP_ENODEV;
+    }
+    return DGRP_OK;
+}
+
+// deepgrp/sequence.pyx:27-30
+DGRP_EXPORT int dgrp_strip_n(const uint8_t *h_seq, int64_t len, int64_t *startpos, int64_t *kept)
+{
+    DGRP_REQUIRE(len >= 0 && startpos && kept && (len == 0 || h_seq), "dgrp_strip_n: bad arguments");
+    int64_t st = 0, en = len;
+    while (st < len && h_seq[st] == 'N') ++st;
+    while (en > 0 && h_seq[en - 1] == 'N') --en;
+    *startpos = st;
+    *kept = en - st;
+    return DGRP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Fragment packing (host).  Operand lane maps of gfx950:
+//   v_mfma_f32_32x32x16_f16   B: lane l, element j  <->  B[k = 8*(l>>5) + j][col = l & 31]
+//   v_mfma_f32_16x16x32_f16   B: lane l, element j  <->  B[k = 8*(l>>4) + j][col = l & 15]
+// ------------------------------------------------------------------------------------------
+static inline uint16_t f2h(float v)
+{
+    _Float16 h = (_Float16)v;
+    uint16_t b;
+    memcpy(&b, &h, 2);
+    return b;
+}
+static inline float h2f(uint16_t b)
+{
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return (float)h;
+}
+
+DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *kernel,
+                                  const float *rec, const float *bias, const float *scale, const float *ffk,
+                                  const float *ffb)
+{
+    DGRP_REQUIRE(out, "dgrp_model_create: NULL out");
+    *out = nullptr;
+    DGRP_REQUIRE(T >= 1 && T <= 65535, "dgrp_model_create: window size %d out of range", T);
+    DGRP_REQUIRE(u >= 1 && u <= 128, "dgrp_model_create: units=%d not supported (1..128)", u);
+    DGRP_REQUIRE(C >= 2 && C <= 16, "dgrp_model_create: classes=%d not supported (2..16)", C);
+    DGRP_REQUIRE(kernel && rec && bias && ffk && ffb && (!attention || scale), "dgrp_model_create: NULL tensor");
+    char nm[8];
+    int rc = dgrp_device_info(nm, sizeof(nm), nullptr, nullptr);
+    if (rc != DGRP_OK) return rc;
+
+    dgrp_model *m = new dgrp_model();
+    m->T = T; m->u = u; m->C = C; m->attention = attention ? 1 : 0;
+    m->UP = (u + 31) / 32 * 32;
+    m->NW = m->UP / 32;
+    m->KS = m->UP / 16;
+    m->nfrag = 3 * (m->KS + 1) + 3;
+    m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr;
+    const int KS = m->KS, NF = m->nfrag, u3 = 3 * u;
+
+    std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
+    auto at = [&](int w, int f, int l, int j) -> uint16_t & { return pack[(((size_t)w * NF + f) * 64 + l) * 8 + j]; };
+    for (int w = 0; w < m->NW; ++w) {
+        for (int l = 0; l < 64; ++l) {
+            const int unit = 32 * w + (l & 31);
+            const bool uok = unit < u;
+            for (int g = 0; g < 3; ++g) {
+                // recurrent part: k-steps 0..KS-1
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 16 * ks + 8 * (l >> 5) + j;
+                        at(w, g * (KS + 1) + ks, l, j) = (uok && k < u) ? f2h(rec[(size_t)k * u3 + g * u + unit]) : 0;
+                    }
+                // input part (k-step KS): rows 0-4 kernel hi, 5 bias hi | rows 8-12 kernel lo, 13 bias lo.
+                // z and r carry the whole input projection and both biases; the h gate's fragment only
+                // the RECURRENT bias (it sits inside r * (...)), its input projection is the Bxh fragment.
+                for (int j = 0; j < 8; ++j) {
+                    float v = 0.0f;
+                    if (uok) {
+                        if (j < 5) v = g < 2 ? kernel[(size_t)j * u3 + g * u + unit] : 0.0f;
+                        else if (j == 5) v = g < 2 ? (float)((double)bias[g * u + unit] + (double)bias[u3 + g * u + unit])
+                                                   : bias[u3 + 2 * u + unit];
+                    }
+                    const uint16_t hi = f2h(v);
+                    at(w, g * (KS + 1) + KS, l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
+                }
+            }
+            for (int j = 0; j < 8; ++j) {                                   // Bxh
+                float v = 0.0f;
+                if (uok) {
+                    if (j < 5) v = kernel[(size_t)j * u3 + 2 * u + unit];
+                    else if (j == 5) v = bias[2 * u + unit];
+                }
+                const uint16_t hi = f2h(v);
+                at(w, 3 * (KS + 1), l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
+            }
+            // dense (16x16x32): 0.5 * FF kernel rows of this wave's 32 units; attention: the avg half
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * (l >> 4) + j, du = 32 * w + k, c = l & 15;
+                float v = 0.0f;
+                if (du < u && c < C) v = 0.5f * ffk[(size_t)((attention ? u : 0) + du) * C + c];
+                const uint16_t hi = f2h(v);
+                at(w, 3 * (KS + 1) + 1, l, j) = hi;
+                at(w, 3 * (KS + 1) + 2, l, j) = f2h(v - h2f(hi));
+            }
+        }
+    }
+    float ffb16[16] = { 0 };
+    for (int c = 0; c < C; ++c) ffb16[c] = ffb[c];
+
+#define CREATE_HIP(call)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            dgrp_set_error("%s failed: %s", #call, hipGetErrorString(e_));                 \
+            dgrp_model_destroy(m);                                                         \
+            return DGRP_EHIP;                                                              \
+        }                                                                                  \
+    } while (0)
+    CREATE_HIP(hipMalloc((void **)&m->d_pack, pack.size() * 2));
+    CREATE_HIP(hipMemcpy(m->d_pack, pack.data(), pack.size() * 2, hipMemcpyHostToDevice));
+    CREATE_HIP(hipMalloc((void **)&m->d_ffb, sizeof(ffb16)));
+    CREATE_HIP(hipMemcpy(m->d_ffb, ffb16, sizeof(ffb16), hipMemcpyHostToDevice));
+    if (attention) {
+        std::vector<float> sc(m->UP, 0.0f), wtop((size_t)m->UP * 16, 0.0f);
+        for (int k = 0; k < u; ++k) {
+            sc[k] = scale[k];
+            for (int c = 0; c < C; ++c) wtop[(size_t)k * 16 + c] = ffk[(size_t)k * C + c];
+        }
+        CREATE_HIP(hipMalloc((void **)&m->d_scale, sc.size() * 4));
+        CREATE_HIP(hipMemcpy(m->d_scale, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        CREATE_HIP(hipMalloc((void **)&m->d_wtop, wtop.size() * 4));
+        CREATE_HIP(hipMemcpy(m->d_wtop, wtop.data(), wtop.size() * 4, hipMemcpyHostToDevice));
+    }
+#undef CREATE_HIP
+    *out = m;
+    return DGRP_OK;
+}
+
+DGRP_EXPORT int dgrp_model_destroy(dgrp_model *m)
+{
+    if (!m) return DGRP_OK;
+    if (m->d_pack) (void)hipFree(m->d_pack);
+    if (m->d_ffb) (void)hipFree(m->d_ffb);
+    if (m->d_scale) (void)hipFree(m->d_scale);
+    if (m->d_wtop) (void)hipFree(m->d_wtop);
+    delete m;
+    return DGRP_OK;
+}
+
+DGRP_EXPORT int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int *attention)
+{
+    DGRP_REQUIRE(m, "dgrp_model_dims: NULL model");
+    if (T) *T = m->T;
+    if (u) *u = m->u;
+    if (C) *C = m->C;
+    if (attention) *attention = m->attention;
+    return DGRP_OK;
+}
+
+// attention keeps avg[t] (fp32 [nw,T,UP]) and the avg half of the logits ([nw,T,C]) between kernels
+DGRP_EXPORT int64_t dgrp_forward_workspace_bytes(const dgrp_model *m, int64_t nw)
+{
+    if (!m || nw < 0) return 0;
+    if (!m->attention) return 256;
+    return dgrp_align_up(nw * m->T * (int64_t)m->UP * 4, 256) + dgrp_align_up(nw * m->T * (int64_t)m->C * 4, 256);
+}
+
+static int forward_common(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch, int64_t w0,
+                          int64_t nw, int merge, float *d_out, void *d_work, int64_t work_bytes, hipStream_t stream)
+{
+    DGRP_REQUIRE(m && s >= 1 && w0 >= 0 && nw >= 0 && n >= 0, "dgrp_forward: bad arguments");
+    if (nw == 0) return DGRP_OK;
+    DGRP_REQUIRE(d_idx && d_out, "dgrp_forward: NULL pointer");
+    DGRP_REQUIRE((w0 + nw - 1) * s + m->T <= n, "dgrp_forward: window %lld (start %lld) runs past n=%lld",
+                 (long long)(w0 + nw - 1), (long long)((w0 + nw - 1) * s), (long long)n);
+    dgrp_placement place = { 0, 0 };
+    if (merge) {
+        DGRP_REQUIRE(batch >= 1, "dgrp_forward_merge: batch must be >= 1");
+        const int64_t total = dgrp_window_count(n, m->T, s);
+        DGRP_REQUIRE(w0 + nw <= total, "dgrp_forward_merge: windows %lld..%lld exceed the record's %lld",
+                     (long long)w0, (long long)(w0 + nw), (long long)total);
+        place = dgrp_make_placement(total, batch);
+    }
+    if (!m->attention) return dgrp_gru_launch(m, d_idx, n, s, place, w0, nw, merge ? 0 : 1, d_out, nullptr, stream);
+    if (work_bytes < dgrp_forward_workspace_bytes(m, nw) || !d_work) {
+        dgrp_set_error("dgrp_forward: attention model needs %lld bytes of workspace for %lld windows",
+                       (long long)dgrp_forward_workspace_bytes(m, nw), (long long)nw);
+        return DGRP_ENOMEM;
+    }
+    float *avg = (float *)d_work;
+    float *pl = (float *)((char *)d_work + dgrp_align_up(nw * m->T * (int64_t)m->UP * 4, 256));
+    int rc = dgrp_gru_launch(m, d_idx, n, s, place, w0, nw, 2, pl, avg, stream);
+    if (rc) return rc;
+    return dgrp_attention_launch(m, s, place, w0, nw, merge, n, avg, pl, d_out, stream);
+}
+
+DGRP_EXPORT int dgrp_forward_windows(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t w0,
+                                     int64_t nw, float *d_probs, void *d_work, int64_t work_bytes, void *stream)
+{
+    return forward_common(m, d_idx, n, s, 1, w0, nw, 0, d_probs, d_work, work_bytes, (hipStream_t)stream);
+}
+
+DGRP_EXPORT int dgrp_forward_merge(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch,
+                                   int64_t w0, int64_t nw, float *d_out, void *d_work, int64_t work_bytes, void *stream)
+{
+    return forward_common(m, d_idx, n, s, batch, w0, nw, 1, d_out, d_work, work_bytes, (hipStream_t)stream);
+}

@@ -1,0 +1,23 @@
+// Device-resident model: the Keras tensors of deepgrp/model.py:293-336 re-laid out as MFMA
+// operand fragments (see gru_kernel.hip for the layout each fragment follows).
+#pragma once
+#include "dgrp_common.h"
+
+struct dgrp_model {
+    int T, u, C, attention;
+    int UP;      // units padded to a multiple of 32
+    int NW;      // waves per workgroup = UP / 32, one 32-unit column slice of every gate per wave
+    int KS;      // 16-deep k-steps of the recurrent contraction = UP / 16
+    int nfrag;   // fragments per wave: 3*(KS+1) gate fragments + x->h~ + dense hi + dense lo
+    uint4 *d_pack;    // [NW][nfrag][64] 8 x fp16 per lane
+    float *d_ffb;     // [16] dense bias, zero padded
+    float *d_scale;   // [UP] attention scale (zero padded) or NULL
+    float *d_wtop;    // [UP][16] rows of the dense kernel that multiply the context vector, or NULL
+};
+
+// rows of LDS the fused kernel may use to pre-merge a workgroup's windows
+int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
+                    int64_t w0, int64_t nw, int mode, float *d_out, float *d_avg, hipStream_t stream);
+int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
+                          int merge, int64_t n, const float *d_avg, const float *d_pl, float *d_out,
+                          hipStream_t stream);

@@ -1,0 +1,400 @@
+// A4 (+A5/A6 fused): the model forward of deepgrp/model.py:293-336 as one CDNA4 kernel.
+//
+//   x [T,5] one-hot --+--> GRU --> fwd[t] --+
+//                     |                     +--> avg[t] = (fwd[t] + rc[t]) / 2 --> Dense --> Softmax
+//   reverse-complement --> GRU --> rc[t]  --+      (same layer object => shared weights; rc is NOT
+//                                                   re-reversed: model.py:309-312, :321-323)
+//
+// Work decomposition (u <= 128; UP = u rounded up to 32, NW = UP/32 waves per workgroup):
+//   * a workgroup owns 16 consecutive windows = 32 recurrent rows (rows 0-15 the windows, rows
+//     16-31 their reverse complements), i.e. one 32-row MFMA tile, for all T steps;
+//   * wave w owns hidden units [32w, 32w+32) of ALL THREE gates, so z, r and the candidate of one
+//     (row, unit) land in the same lane/register of three accumulators and the gate math needs no
+//     cross-lane traffic;
+//   * the wave's slice of the recurrent kernel U (K = UP rows x 96 columns) lives in VGPRs for the
+//     whole kernel as v_mfma_f32_32x32x16_f16 B fragments (112 VGPRs at u = 128) -- nothing but
+//     the 8 KB hidden-state tile moves per step, through LDS;
+//   * the input projection is one extra 16-deep k-step: A = one-hot(base) with a constant-1 column,
+//     B rows = kernel rows and biases, each split into fp16 hi + lo parts (exact products, fp32
+//     accumulate => ~fp32-exact projection for free);
+//   * the candidate's  x.W_h + b  lands on top of  r * (h.U_h + b_rec)  by feeding r*g as the C
+//     operand of that MFMA -- no separate accumulator;
+//   * Dense(C) is two v_mfma_f32_16x16x32_f16 per wave per step on the wave's own 32 units of the
+//     fresh hidden tile (fwd rows accumulate onto rc rows = the Average), partial sums meet in LDS
+//     and a rotating "duty" wave adds them, applies the softmax and max-merges into a per-workgroup
+//     LDS image of the [rows, C] output (get_max, deepgrp/maxcalc.c:10-24), flushed once at the end
+//     with full-line atomic max (probabilities are >= 0, so unsigned-int max == float max).
+//
+// Roofline: 12 u^2 T flop per window on the MFMA pipe, but 6 transcendentals per (row, unit, step)
+// on the VALU pipe are of the same order; two workgroups per CU let one's MFMAs
+// overlap the other's gate math.
+#include "dgrp_model.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DGRP_WG_WINDOWS 16
+
+struct gru_params {
+    const uint8_t *idx;   // class index per base [n]
+    int64_t n, s, w0, nw; // this launch covers windows w0 .. w0+nw-1 (absolute indices)
+    dgrp_placement place;
+    const uint4 *pack;
+    const float *ffb;
+    float *out;           // mode 0: merged [n, C]; mode 1: probs [nw, T, C]; mode 2: logits part [nw, T, C]
+    float *avg;           // mode 2: [nw, T, UP]
+    int T, C, nfrag, mode;
+    int Tp;               // T rounded up to 16 (row pitch of the staged sequences)
+    int ospan;            // rows of the LDS output image (mode 0), 0 = none
+};
+
+__device__ __forceinline__ float fast_sigmoid(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// LDS carve (bytes) -- shared by host and device
+__host__ __device__ static inline int gru_lds_hbuf(int UP) { return 2 * 32 * (UP + 8) * 2; }
+__host__ __device__ static inline int gru_lds_dpart(int NW) { return 2 * NW * 64 * 16; }
+__host__ __device__ static inline int gru_lds_seq(int Tp) { return DGRP_WG_WINDOWS * Tp; }
+__host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 8 + DGRP_WG_WINDOWS * 4; }
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params p)
+{
+    constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;   // HS: padded row pitch (halves) -> conflict-free b128 reads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16 *hbuf = reinterpret_cast<_Float16 *>(smem);
+    f32x4 *dpart = reinterpret_cast<f32x4 *>(smem + gru_lds_hbuf(UP));
+    uint8_t *seqs = smem + gru_lds_hbuf(UP) + gru_lds_dpart(NW);
+    int64_t *row0s = reinterpret_cast<int64_t *>(seqs + gru_lds_seq(p.Tp));
+    int *rowoff = reinterpret_cast<int *>(row0s + DGRP_WG_WINDOWS);
+    unsigned *obuf = reinterpret_cast<unsigned *>(rowoff + DGRP_WG_WINDOWS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, C = p.C;
+    const int64_t wg_w = p.w0 + (int64_t)blockIdx.x * DGRP_WG_WINDOWS;   // first window of this workgroup
+    const int nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - wg_w);
+
+    // ---- resident B fragments ------------------------------------------------------------
+    const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
+    half8 Bz[KS + 1], Br[KS + 1], Bg[KS + 1], Bxh, Bd_hi, Bd_lo;
+#pragma unroll
+    for (int k = 0; k <= KS; ++k) {
+        uint4 a = mypack[(size_t)(k) * 64], b = mypack[(size_t)(KS + 1 + k) * 64], c = mypack[(size_t)(2 * (KS + 1) + k) * 64];
+        Bz[k] = __builtin_bit_cast(half8, a);
+        Br[k] = __builtin_bit_cast(half8, b);
+        Bg[k] = __builtin_bit_cast(half8, c);
+    }
+    Bxh = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1)) * 64]);
+    Bd_hi = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 1) * 64]);
+    Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 2) * 64]);
+
+    // ---- stage sequences, placement rows, zero state ---------------------------------------
+    for (int i = tid; i < DGRP_WG_WINDOWS * T; i += 64 * NW) {
+        const int wi = i / T, t = i - wi * T;
+        seqs[wi * p.Tp + t] = wi < nvalid ? p.idx[(wg_w + wi) * p.s + t] : (uint8_t)4;
+    }
+    for (int i = tid; i < 32 * HS; i += 64 * NW) hbuf[i] = (_Float16)0.0f;          // h_{-1} = 0
+    int64_t lo = 0;
+    if (p.mode == 0) {
+        // smallest placement row of the workgroup; with the partial-batch shift the order of rows
+        // is still monotone inside each of the two regimes, so min is at one of the two ends
+        int64_t a = dgrp_place_row(p.place, wg_w, p.s), b = dgrp_place_row(p.place, wg_w + nvalid - 1, p.s);
+        lo = a < b ? a : b;
+        for (int i = tid; i < p.ospan * C; i += 64 * NW) obuf[i] = 0u;
+    }
+    if (tid < DGRP_WG_WINDOWS) {
+        int64_t r0 = -1;
+        int off = -1;
+        if (tid < nvalid) {
+            r0 = p.mode == 0 ? dgrp_place_row(p.place, wg_w + tid, p.s) : (wg_w + tid - p.w0) * (int64_t)T;
+            if (p.mode == 0 && r0 - lo + T <= p.ospan) off = (int)(r0 - lo);
+        }
+        row0s[tid] = r0;
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+
+    const int r = lane & 31;            // recurrent row of this lane's A fragment
+    const int wi_a = r & 15;            // its window
+    const int dir = r >> 4;             // 0: window as is, 1: reverse complement
+    const int khalf = lane >> 5;        // which 8 of a 16-deep k-step this lane feeds
+    const uint8_t *myseq = seqs + wi_a * p.Tp;
+
+    float h[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[i] = 0.0f;
+
+    _Float16 *hcur = hbuf, *hnxt = hbuf + 32 * HS;
+    const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const f32x4 zero4 = { 0, 0, 0, 0 };
+
+    // softmax + merge of step `t`'s partial logits (run by one wave after the step's barrier)
+    auto finish_step = [&](int t) {
+        const f32x4 *dp = dpart + (size_t)(t & 1) * NW * 64 + lane;
+        f32x4 sum = dp[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sum += dp[w * 64];
+        const int c = lane & 15;
+        const float bias = c < C ? p.ffb[c] : 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int wi = 4 * (lane >> 4) + reg;
+            float lg = c < C ? sum[reg] + bias : -INFINITY;
+            float val;
+            if (p.mode == 2) {
+                val = lg;                                     // attention: softmax happens later
+            } else {
+                float m = lg;
+                m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
+                m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
+                float e = c < C ? __expf(lg - m) : 0.0f;
+                float ssum = e;
+                ssum += __shfl_xor(ssum, 1); ssum += __shfl_xor(ssum, 2);
+                ssum += __shfl_xor(ssum, 4); ssum += __shfl_xor(ssum, 8);
+                val = e / ssum;
+            }
+            const int64_t r0 = row0s[wi];
+            if (c < C && r0 >= 0) {
+                if (p.mode == 0) {
+                    const int off = rowoff[wi];
+                    if (off >= 0) atomicMax(&obuf[(off + t) * C + c], __float_as_uint(val));
+                    else if (r0 + t < p.n) atomicMax(reinterpret_cast<unsigned *>(p.out) + (r0 + t) * C + c, __float_as_uint(val));
+                } else {
+                    p.out[(r0 + t) * C + c] = val;
+                }
+            }
+        }
+    };
+
+    for (int t = 0; t < T; ++t) {
+        if (t > 0 && wave == (t - 1) % NW) finish_step(t - 1);
+
+        // ---- A operand of the input k-step: one-hot(base) | 1 ------------------------------
+        uint32_t b = myseq[dir ? T - 1 - t : t];
+        if (dir) b = b < 4 ? 3 - b : 4;                      // complement table [3,2,1,0,4], model.py:233-237
+        const uint32_t one = 0x3C00u << ((b & 1) * 16);
+        const uint32_t sel = b >> 1;
+        const uint4 xu = make_uint4(sel == 0 ? one : 0u, sel == 1 ? one : 0u, (sel == 2 ? one : 0u) | 0x3C000000u, 0u);
+        const half8 xa = __builtin_bit_cast(half8, xu);
+
+        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bz[KS], zero16, 0, 0, 0);
+        f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Br[KS], zero16, 0, 0, 0);
+        f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bg[KS], zero16, 0, 0, 0);
+        const _Float16 *arow = hcur + r * HS + 8 * khalf;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const half8 a = *reinterpret_cast<const half8 *>(arow + 16 * k);
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Br[k], ar, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bg[k], ag, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bz[k], az, 0, 0, 0);
+        }
+        // ---- gates (Keras GRUCell, reset_after=True) ---------------------------------------
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ag[i] *= fast_sigmoid(ar[i]);          // r * (h.U_h + b_rec_h)
+        ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bxh, ag, 0, 0, 0);    // + x.W_h + b_in_h
+#pragma unroll
+        for (int i = 0; i < 16; ++i) az[i] = fast_sigmoid(az[i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float hh = fast_tanh(ag[i]);
+            h[i] = hh + az[i] * (h[i] - hh);                                 // z*h + (1-z)*hh
+        }
+        // ---- publish h_t (fp16) for the next step's A operand ------------------------------
+        _Float16 *wcol = hnxt + 32 * wave + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * khalf;            // 32x32 C/D layout
+            wcol[row * HS] = (_Float16)h[i];
+        }
+        if (p.mode == 2) {
+            // attention: keep avg[t] (fp32) for the second kernel
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int wi = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+                if (wi < nvalid)
+                    p.avg[((wg_w + wi - p.w0) * (int64_t)T + t) * UP + 32 * wave + (lane & 31)] = 0.5f * (h[i] + h[i + 8]);
+            }
+        }
+        // ---- Dense on this wave's 32 units: rows r (window) and r+16 (its rc) accumulate ------
+        {
+            const _Float16 *drow = hnxt + (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
+            const half8 a0 = *reinterpret_cast<const half8 *>(drow);
+            const half8 a1 = *reinterpret_cast<const half8 *>(drow + 16 * HS);
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
+            dpart[(size_t)(t & 1) * NW * 64 + wave * 64 + lane] = d;
+        }
+        __syncthreads();
+        _Float16 *tmp = hcur; hcur = hnxt; hnxt = tmp;
+    }
+    if (wave == (T - 1) % NW) finish_step(T - 1);
+
+    if (p.mode == 0 && p.ospan > 0) {
+        __syncthreads();
+        // flush the pre-merged image: contiguous rows -> 256-byte atomic wave-instructions
+        unsigned *gout = reinterpret_cast<unsigned *>(p.out) + lo * C;
+        const int64_t lim = (p.n - lo) * C;
+        for (int i = tid; i < p.ospan * C; i += 64 * NW) {
+            const unsigned v = obuf[i];
+            if (v != 0u && i < lim) atomicMax(gout + i, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// AdditiveAttention(use_scale=True) + Dense + Softmax for the attention model
+// (model.py:309-319, :325-329).  One workgroup per window over the avg[t] tile kept by mode 2.
+//   q = avg-of-final-states = avg[T-1];  e[t] = sum_k scale[k] tanh(q[k] + avg[t,k]);
+//   a = softmax_t(e);  ctx = sum_t a[t] avg[t];  logits[t] = ctx.W_top + (avg[t].W_bot + b)
+// ------------------------------------------------------------------------------------------
+struct att_params {
+    const float *avg;    // [nw, T, UP]
+    const float *pl;     // [nw, T, C]  avg[t].W_bot + b  from the GRU kernel
+    const float *scale;  // [UP]
+    const float *wtop;   // [UP, 16]
+    float *out;
+    int64_t n, s, w0, nw;
+    dgrp_placement place;
+    int T, C, UP, merge;
+};
+
+__global__ void __launch_bounds__(256) attention_kernel(const att_params p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *q = reinterpret_cast<float *>(smem);          // [UP]
+    float *ctx = q + p.UP;                               // [UP]
+    float *e = ctx + p.UP;                               // [T]
+    float *red = e + p.T;                                // [16]
+    float *cl = red + 16;                                // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = p.T, UP = p.UP, C = p.C;
+    const int64_t wl = blockIdx.x;                       // window relative to w0
+    const float *avg = p.avg + wl * (int64_t)T * UP;
+
+    for (int k = tid; k < UP; k += 256) q[k] = avg[(int64_t)(T - 1) * UP + k];
+    __syncthreads();
+    for (int t = wave; t < T; t += 4) {
+        float acc = 0.0f;
+        for (int k = lane; k < UP; k += 64) acc += p.scale[k] * fast_tanh(q[k] + avg[(int64_t)t * UP + k]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) e[t] = acc;
+    }
+    __syncthreads();
+    // softmax over t
+    float m = -INFINITY;
+    for (int t = tid; t < T; t += 256) m = fmaxf(m, e[t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float ssum = 0.0f;
+    for (int t = tid; t < T; t += 256) { float v = __expf(e[t] - m); e[t] = v; ssum += v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
+    __syncthreads();
+    if (lane == 0) red[8 + wave] = ssum;
+    __syncthreads();
+    const float inv = 1.0f / (red[8] + red[9] + red[10] + red[11]);
+    for (int k = tid; k < UP; k += 256) {
+        float acc = 0.0f;
+        for (int t = 0; t < T; ++t) acc += e[t] * avg[(int64_t)t * UP + k];
+        ctx[k] = acc * inv;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float acc = 0.0f;
+        if (tid < C)
+            for (int k = 0; k < UP; ++k) acc += ctx[k] * p.wtop[k * 16 + tid];
+        cl[tid] = acc;
+    }
+    __syncthreads();
+    const int64_t w = p.w0 + wl;
+    const int64_t row0 = p.merge ? dgrp_place_row(p.place, w, p.s) : wl * (int64_t)T;
+    const float *pl = p.pl + wl * (int64_t)T * C;
+    for (int t = tid; t < T; t += 256) {
+        float lg[16];
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) { lg[c] = pl[t * C + c] + cl[c]; mx = fmaxf(mx, lg[c]); }
+        float den = 0.0f;
+        for (int c = 0; c < C; ++c) { lg[c] = __expf(lg[c] - mx); den += lg[c]; }
+        for (int c = 0; c < C; ++c) {
+            const float v = lg[c] / den;
+            if (p.merge) {
+                if (row0 + t < p.n) atomicMax(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
+            } else {
+                p.out[(row0 + t) * C + c] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int NW>
+static int launch_gru(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
+{
+    DGRP_HIP(hipFuncSetAttribute((const void *)gru_fused_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gru_fused_kernel<NW>, dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
+int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
+                    int64_t w0, int64_t nw, int mode, float *d_out, float *d_avg, hipStream_t stream)
+{
+    if (nw <= 0) return DGRP_OK;
+    gru_params p;
+    p.idx = d_idx; p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
+    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = d_avg;
+    p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = mode;
+    p.Tp = (int)dgrp_align_up(m->T, 16);
+    const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
+    p.ospan = 0;
+    if (mode == 0) {
+        // rows spanned by 16 consecutive windows, capped so that two workgroups fit a CU's 160 KiB
+        const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
+        const int64_t cap = (72 * 1024 - fixed) / (m->C * 4);
+        p.ospan = (int)(want < cap ? want : cap);
+        if (p.ospan < m->T) p.ospan = 0;
+    }
+    const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
+    const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
+    DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
+    switch (m->NW) {
+    case 1: return launch_gru<1>(p, groups, lds, stream);
+    case 2: return launch_gru<2>(p, groups, lds, stream);
+    case 3: return launch_gru<3>(p, groups, lds, stream);
+    case 4: return launch_gru<4>(p, groups, lds, stream);
+    default:
+        dgrp_set_error("units=%d not supported by the register-resident GRU kernel (max 128)", m->u);
+        return DGRP_EINVAL;
+    }
+}
+
+int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
+                          int merge, int64_t n, const float *d_avg, const float *d_pl, float *d_out,
+                          hipStream_t stream)
+{
+    if (nw <= 0) return DGRP_OK;
+    att_params p;
+    p.avg = d_avg; p.pl = d_pl; p.scale = m->d_scale; p.wtop = m->d_wtop; p.out = d_out;
+    p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
+    p.T = m->T; p.C = m->C; p.UP = m->UP; p.merge = merge;
+    const size_t lds = (size_t)(2 * m->UP + m->T + 32) * sizeof(float);
+    DGRP_REQUIRE(nw < (1ll << 31), "too many windows in one launch");
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)nw), dim3(256), lds, stream, p);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}

@@ -1,0 +1,696 @@
+// Post-processing kernels: score transform (A7), softmax path (A8), maximal scoring segments
+// with x-drop (A9/A10) and run-length segment extraction (A11).  Compiled with
+// -ffp-contract=off: the float32/float64 expressions below must round exactly where the
+// reference's numpy / C code rounds.
+#include "dgrp_common.h"
+
+#include <math.h>
+
+// ------------------------------------------------------------------------------------------
+// numpy's float32 log and exp (the routines np.log / np.exp run on a float32 array on any
+// AVX2/AVX512F host: numpy/core/src/umath/loops_exponent_log.dispatch.c.src).  They are not
+// correctly rounded, but they are plain fma chains, so they can be reproduced bit for bit --
+// which is what makes the scores of deepgrp/prediction.py:55 reproducible at all.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float np_logf(float xin)
+{
+    // callers pass finite positive normal numbers (m / (1 - m) with m in [1e-6, 0.99])
+    const uint32_t bits = __float_as_uint(xin);
+    float k = (float)((int)(bits >> 23) - 126);
+    float m = __uint_as_float((bits & 0x007fffffu) | 0x3f000000u);          // [0.5, 1)
+    if (m <= 0.70710678118654752440f) { m = m + m; k = k - 1.0f; }
+    const float x = m - 1.0f;
+    float den = fmaf(5.875095403124574342950e-03f, x, 1.546476374983906719538e-01f);
+    den = fmaf(den, x, 9.864942958519418960339e-01f);
+    den = fmaf(den, x, 2.453006071784736363091e+00f);
+    den = fmaf(den, x, 2.612677543073109236779e+00f);
+    den = fmaf(den, x, 1.0f);
+    float num = fmaf(2.589979117907922693523e-02f, x, 3.808837741388407920751e-01f);
+    num = fmaf(num, x, 1.480000633576506585156e+00f);
+    num = fmaf(num, x, 2.112677543073053063722e+00f);
+    num = fmaf(num, x, 9.999999999999998702752e-01f);
+    num = fmaf(num, x, 0.0f);
+    return fmaf(k, 0.693147180559945309417232121458176568f, __fdiv_rn(num, den));
+}
+
+__device__ __forceinline__ float np_expf(float x)
+{
+    if (x != x) return x;
+    if (x >= 88.72283905206835f) return INFINITY;
+    if (x <= -103.97208f) return 0.0f;
+    const float q = rintf(x * 1.44269504088896340736f);
+    float r = fmaf(q, -6.93145752e-1f, x);
+    r = fmaf(q, -1.42860677e-6f, r);
+    float num = fmaf(5.082762527590693718096e-04f, r, 6.757896990527504603057e-03f);
+    num = fmaf(num, r, 5.114512081637298353406e-02f);
+    num = fmaf(num, r, 2.473615434895520810817e-01f);
+    num = fmaf(num, r, 7.257664613233124478488e-01f);
+    num = fmaf(num, r, 9.999999999980870924916e-01f);
+    float den = fmaf(2.159509375685829852307e-02f, r, -2.742335390411667452936e-01f);
+    den = fmaf(den, r, 1.0f);
+    return ldexpf(__fdiv_rn(num, den), (int)q);
+}
+
+static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8)
+{
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------
+// A7  deepgrp/prediction.py:51-57, all in float32 like numpy, widened at the end
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) scores_kernel(const float *__restrict__ probs, int64_t n, int C,
+                                                     double *__restrict__ scores, int8_t *__restrict__ cls)
+{
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+        const float *p = probs + i * C;
+        int a = 0;
+        float mx = p[0];
+        for (int c = 1; c < C; ++c) {
+            const float v = p[c];
+            if (v > mx) { mx = v; a = c; }                    // argmax keeps the first maximum
+        }
+        float m = mx + 1e-6f;                                 // probs.max(axis=1) + 1e-6
+        if (m > 0.99f) m = 0.99f;                             // mins[mins > 0.99] = 0.99
+        const float t = np_logf(__fdiv_rn(m, 1.0f - m));      // np.log(mins / (1 - mins))
+        const float sc = a > 0 ? t : -10.0f * t;              // np.where(cls > 0, t, -10 * t)
+        scores[i] = (double)sc;                               // .astype(float)
+        cls[i] = (int8_t)a;
+    }
+}
+
+DGRP_EXPORT int dgrp_scores(const float *d_probs, int64_t n, int C, double *d_scores, int8_t *d_cls, void *stream)
+{
+    DGRP_REQUIRE(n >= 0 && C >= 1 && C <= 16, "dgrp_scores: bad n/C");
+    if (n == 0) return DGRP_OK;
+    DGRP_REQUIRE(d_probs && d_scores && d_cls, "dgrp_scores: NULL pointer");
+    hipLaunchKernelGGL(scores_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, d_probs, n,
+                       C, d_scores, d_cls);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// A8  deepgrp/prediction.py:62-65 + deepgrp/__main__.py:83
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) blockmax_kernel(const float *__restrict__ a, int64_t total, float *__restrict__ part)
+{
+    __shared__ float red[4];
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    float m = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += nthreads) m = fmaxf(m, a[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ void __launch_bounds__(256) softmax_labels_kernel(const float *__restrict__ a, int64_t n, int C,
+                                                             const float *__restrict__ part, int nparts,
+                                                             float *__restrict__ sm, int8_t *__restrict__ labels)
+{
+    float gmax = -INFINITY;
+    for (int i = 0; i < nparts; ++i) gmax = fmaxf(gmax, part[i]);
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
+        float e[16];
+        float sum = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            e[c] = np_expf(a[i * C + c] - gmax);
+            sum = c == 0 ? e[0] : sum + e[c];                 // numpy folds a short row left to right
+        }
+        int best = 0;
+        float bv = __fdiv_rn(e[0], sum);
+        if (sm) sm[i * C] = bv;
+        for (int c = 1; c < C; ++c) {
+            const float v = __fdiv_rn(e[c], sum);
+            if (sm) sm[i * C + c] = v;
+            if (v > bv) { bv = v; best = c; }
+        }
+        labels[i] = (int8_t)best;
+    }
+}
+
+DGRP_EXPORT int dgrp_softmax_labels(const float *d_probs, int64_t n, int C, float *d_softmax, int8_t *d_labels,
+                                    void *d_work, int64_t work_bytes, void *stream)
+{
+    DGRP_REQUIRE(n >= 0 && C >= 1 && C <= 16, "dgrp_softmax_labels: bad n/C");
+    if (n == 0) return DGRP_OK;
+    const int nparts = 1024;
+    DGRP_REQUIRE(d_probs && d_labels && d_work && work_bytes >= (int64_t)(nparts * sizeof(float)),
+                 "dgrp_softmax_labels: need %d bytes of workspace", (int)(nparts * sizeof(float)));
+    float *part = (float *)d_work;
+    hipLaunchKernelGGL(blockmax_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, d_probs, n * C, part);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(softmax_labels_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       d_probs, n, C, part, nparts, d_softmax, d_labels);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Device-wide exclusive scan of uint64 (two packed 32-bit counters never overflow into each
+// other for n < 2^31).  Three launches: tile sums, single-workgroup scan of the sums, apply.
+// ------------------------------------------------------------------------------------------
+#define SCAN_TILE 2048   // elements per workgroup (256 threads x 8)
+
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *total, uint64_t *lds)
+{
+    // 256 threads; returns the exclusive prefix of v within the workgroup
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    uint64_t base = 0;
+    for (int w = 0; w < wave; ++w) base += lds[w];
+    if (total) *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+__global__ void __launch_bounds__(256) scan_tilesum_kernel(const uint64_t *__restrict__ in, int64_t n, uint64_t *__restrict__ tilesum)
+{
+    __shared__ uint64_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    uint64_t s = 0;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tilesum[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ void __launch_bounds__(256) scan_sums_kernel(uint64_t *__restrict__ tilesum, int64_t ntiles, uint64_t *__restrict__ grand)
+{
+    __shared__ uint64_t lds[4];
+    uint64_t carry = 0;
+    for (int64_t base = 0; base < ntiles; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const uint64_t v = i < ntiles ? tilesum[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = block_exclusive_scan(v, &tot, lds);
+        if (i < ntiles) tilesum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && grand) *grand = carry;
+}
+
+__global__ void __launch_bounds__(256) scan_apply_kernel(const uint64_t *__restrict__ in, int64_t n,
+                                                         const uint64_t *__restrict__ tilesum, uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+    uint64_t v[8], s = 0;
+    for (int j = 0; j < 8; ++j) { v[j] = base + j < n ? in[base + j] : 0; s += v[j]; }
+    uint64_t ex = block_exclusive_scan(s, nullptr, lds) + tilesum[blockIdx.x];
+    for (int j = 0; j < 8; ++j) {
+        if (base + j < n) out[base + j] = ex;
+        ex += v[j];
+    }
+}
+
+// in/out may alias; tiles: workspace of ceil(n / SCAN_TILE) uint64; grand: optional device uint64 total
+static int device_exclusive_scan(const uint64_t *in, uint64_t *out, int64_t n, uint64_t *tiles, uint64_t *grand,
+                                 hipStream_t stream)
+{
+    if (n <= 0) {
+        if (grand) DGRP_HIP(hipMemsetAsync(grand, 0, sizeof(uint64_t), stream));
+        return DGRP_OK;
+    }
+    const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(scan_tilesum_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, in, n, tiles);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, tiles, ntiles, grand);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, in, n, tiles, out);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// A10  mss_find_all (deepgrp/_mss/mss.c:50-101) -- "stretch-parallel, fixed-point" form.
+//
+// The algorithm is a left fold in double precision (L += S[i]); it cannot be re-associated
+// without changing roundings.  What CAN be done exactly: an x-drop reset (mss.c:89-92) returns the
+// scan to a history-free state (stack empty, max = -1e30), and a block of 64 consecutive
+// non-positive scores whose sum is below -(xdrop + 1) forces such a reset inside it whenever the
+// state was not already history-free (the running max is >= L on entry and never grows inside the
+// block).  So right after such a block the only thing the scan remembers is the scalar L.  The
+// sequence is cut into "stretches" at those points, every stretch is scanned by one thread with
+// the reference's exact arithmetic starting from a guessed L, and the guesses are iterated
+// (stretch k starts from the L stretch k-1 ended with in the previous pass) until no stretch's
+// final L changes.  By induction over k the fixed point is exactly the sequential result.  The
+// x-drop reset makes a stretch's final L independent of its initial L whenever it contains a
+// positive score, so two passes are the norm; the worst case (no qualifying block anywhere) is
+// one stretch = the sequential scan on one lane.
+// ------------------------------------------------------------------------------------------
+struct mss_cand { int32_t st, en; double L, R; int32_t pre, pad; };   // mss.c:24-28
+
+struct mss_layout {            // carve of the caller's workspace
+    int64_t nblk;
+    uint64_t *blk;             // [nblk+1] per-64-block packed (boundary flag << 32 | positive-run starts), then scanned
+    uint64_t *tiles;           // scan scratch
+    uint64_t *grand;           // [4]: [0] scan total, [1] changed flag, [2] error flag, [3] total kept segments
+    int64_t *ustart;           // [nunits+1] stretch starts
+    int64_t *urun;             // [nunits+1] first stack/segment slot of each stretch
+    double *exitL[2];          // [nunits] final L of each stretch, ping-pong
+    uint64_t *segcnt;          // [nunits+1] kept segments per stretch, then scanned
+    mss_cand *stack;           // [nruns]
+    int32_t *segs;             // [nruns][2] kept segments in stretch-local slots
+    int32_t *segs_out;         // [nruns][2] compacted
+    int64_t bytes;
+};
+
+static mss_layout mss_carve(void *work, int64_t n)
+{
+    mss_layout l;
+    unsigned char *p = (unsigned char *)work;
+    auto take = [&](int64_t bytes) { unsigned char *q = p; p += dgrp_align_up(bytes, 256); return q; };
+    l.nblk = (n + 63) / 64;
+    const int64_t maxunits = l.nblk + 1, maxruns = n / 2 + 2;
+    l.blk = (uint64_t *)take((l.nblk + 1) * 8);
+    l.tiles = (uint64_t *)take(((maxunits + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 8);
+    l.grand = (uint64_t *)take(64);
+    l.ustart = (int64_t *)take((maxunits + 1) * 8);
+    l.urun = (int64_t *)take((maxunits + 1) * 8);
+    l.exitL[0] = (double *)take(maxunits * 8);
+    l.exitL[1] = (double *)take(maxunits * 8);
+    l.segcnt = (uint64_t *)take((maxunits + 1) * 8);
+    l.stack = (mss_cand *)take(maxruns * (int64_t)sizeof(mss_cand));
+    l.segs = (int32_t *)take(maxruns * 8);
+    l.segs_out = (int32_t *)take(maxruns * 8);
+    l.bytes = p - (unsigned char *)work;
+    return l;
+}
+
+DGRP_EXPORT int64_t dgrp_mss_workspace_bytes(int64_t n)
+{
+    if (n < 0) return 0;
+    return mss_carve(nullptr, n).bytes;
+}
+
+// One wave per 64-block: does the block force an x-drop reset (see above)?  How many positive
+// runs START in it?  Packed as (boundary candidate << 32) | run starts; a candidate becomes a
+// stretch boundary only if the NEXT block contains a positive score (a long background stretch
+// stays with the stretch before it instead of being cut into one trivial stretch per block, which
+// would make the fixed-point iteration crawl one block per pass).
+__global__ void __launch_bounds__(256) mss_blockstat_kernel(const double *__restrict__ S, int64_t n, double thr,
+                                                            uint64_t *__restrict__ blk, uint8_t *__restrict__ flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b * 64 >= n) return;
+    const int64_t i = b * 64 + lane;
+    const double s = i < n ? S[i] : 0.0;
+    const bool pos = i < n && s > 0;
+    const bool prevpos = i > 0 && i < n && S[i - 1] > 0;
+    const unsigned long long mpos = __ballot(pos);
+    const unsigned long long mstart = __ballot(pos && !prevpos);
+    double sum = s;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) {
+        const bool full = b * 64 + 64 <= n;
+        const bool qual = full && mpos == 0ull && thr > 0.0 && sum < -thr;
+        flags[b] = (uint8_t)((qual ? 1 : 0) | (mpos != 0ull ? 2 : 0));
+        blk[b] = (uint64_t)__popcll(mstart);
+    }
+}
+
+__global__ void __launch_bounds__(256) mss_boundary_kernel(const uint8_t *__restrict__ flags, int64_t nblk,
+                                                           uint64_t *__restrict__ blk)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblk) return;
+    const bool boundary = (flags[b] & 1) && b + 1 < nblk && (flags[b + 1] & 2);
+    if (boundary) blk[b] |= 1ull << 32;
+}
+
+// after the exclusive scan of blk: block b's entry holds (#boundaries before b, #run starts before b)
+__global__ void __launch_bounds__(256) mss_units_kernel(const uint64_t *__restrict__ blk, const uint8_t *__restrict__ flags,
+                                                        int64_t nblk, int64_t n, int64_t *__restrict__ ustart,
+                                                        int64_t *__restrict__ urun, const uint64_t *__restrict__ grand)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) {
+        ustart[0] = 0;
+        urun[0] = 0;
+        const int64_t nunits = (int64_t)(grand[0] >> 32) + 1;
+        ustart[nunits] = n;
+        urun[nunits] = (int64_t)(grand[0] & 0xffffffffull);
+    }
+    if (b >= nblk) return;
+    const bool boundary = (flags[b] & 1) && b + 1 < nblk && (flags[b + 1] & 2);
+    if (boundary) {
+        const int64_t k = (int64_t)(blk[b] >> 32) + 1;          // this boundary opens stretch k
+        ustart[k] = (b + 1) * 64;
+        // run starts before block b+1 = starts before b + starts in b (none: b is all non-positive)
+        urun[k] = (int64_t)(blk[b] & 0xffffffffull);
+    }
+}
+
+// One thread per stretch, the reference loop verbatim in double precision.
+__global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__ S, const int64_t *__restrict__ ustart,
+                                                      const int64_t *__restrict__ urun, int64_t nunits,
+                                                      const double *__restrict__ exit_prev, double *__restrict__ exit_cur,
+                                                      mss_cand *__restrict__ stack_all, int32_t *__restrict__ segs_all,
+                                                      uint64_t *__restrict__ segcnt, int min_sc, double xdrop,
+                                                      uint64_t *__restrict__ grand, int pass)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nunits) return;
+    const double entry = k == 0 ? 0.0 : exit_prev[k - 1];   // pass 0 reads the zero-initialised buffer
+    const int64_t begin = ustart[k], end = ustart[k + 1];
+    mss_cand *st = stack_all + urun[k];
+    int32_t *segs = segs_all + 2 * urun[k];
+    int64_t nst = 0, nseg = 0;
+    double L = entry, peak = -1e30;
+    const double NEG = -1e30;
+
+    auto flush = [&]() {
+        for (int64_t j = 0; j < nst; ++j) {
+            const double sc = st[j].R - st[j].L;
+            if (sc >= min_sc) { segs[2 * nseg] = st[j].st; segs[2 * nseg + 1] = st[j].en; ++nseg; }
+        }
+        nst = 0;
+    };
+
+    int64_t i = begin;
+    while (i < end) {
+        const double s = S[i];
+        if (s > 0) {
+            double R = L + s;
+            int64_t e = i + 1;
+            while (e < end) {
+                const double v = S[e];
+                if (!(v > 0.)) break;
+                R += v;
+                ++e;
+            }
+            if (R > peak) peak = R;
+            int32_t tst = (int32_t)i;
+            double tL = L;
+            int64_t j;
+            for (;;) {
+                j = nst - 1;
+                while (j >= 0) {
+                    if (st[j].L < tL) break;
+                    const int32_t pre = st[j].pre;
+                    j = pre >= 0 ? pre : j - 1;
+                }
+                if (j >= 0 && st[j].R < R) {
+                    tst = st[j].st;
+                    tL = st[j].L;
+                    nst = j;
+                    continue;
+                }
+                break;
+            }
+            if (j < 0) { flush(); peak = R; }
+            mss_cand c;
+            c.st = tst; c.en = (int32_t)e; c.L = tL; c.R = R; c.pre = (int32_t)j; c.pad = 0;
+            st[nst++] = c;
+            L = R;
+            i = e;
+        } else {
+            if (xdrop > 0.0 && L + s + xdrop < peak) { flush(); L = 0.0; peak = NEG; }
+            L += s;
+            ++i;
+        }
+    }
+    if (k == nunits - 1) {
+        flush();
+    } else if (nst != 0 || peak != NEG) {
+        atomicOr((unsigned long long *)&grand[2], 1ull);    // the forced-reset argument failed: caller falls back
+    }
+    segcnt[k] = (uint64_t)nseg;
+    if (pass == 0 || __double_as_longlong(exit_prev[k]) != __double_as_longlong(L))
+        atomicOr((unsigned long long *)&grand[1], 1ull);
+    exit_cur[k] = L;
+}
+
+__global__ void __launch_bounds__(256) mss_compact_kernel(const int32_t *__restrict__ segs, const int64_t *__restrict__ urun,
+                                                          const uint64_t *__restrict__ segoff, const uint64_t *__restrict__ segcnt_total,
+                                                          int64_t nunits, int32_t *__restrict__ out)
+{
+    // one thread per stretch copies its kept segments to their global slots (order preserved)
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nunits) return;
+    const int64_t from = urun[k];
+    const uint64_t to = segoff[k];
+    const uint64_t cnt = (k + 1 < nunits ? segoff[k + 1] : *segcnt_total) - to;
+    for (uint64_t j = 0; j < cnt; ++j) {
+        out[2 * (to + j)] = segs[2 * (from + j)];
+        out[2 * (to + j) + 1] = segs[2 * (from + j) + 1];
+    }
+}
+
+// A9  deepgrp/_mss/pymss.pyx:57-77: one wave per kept segment: majority label over 1..C-1 (first
+// maximum wins, all-zero segment -> 1), zeros inside the segment take it.
+__global__ void __launch_bounds__(256) mss_vote_kernel(const int32_t *__restrict__ segs, const uint64_t *__restrict__ nseg_p,
+                                                       const int8_t *__restrict__ cls, int nof_labels,
+                                                       int8_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nseg = (int64_t)*nseg_p;
+    for (int64_t sidx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sidx < nseg; sidx += (int64_t)gridDim.x * 4) {
+        const int64_t st = segs[2 * sidx], en = segs[2 * sidx + 1];
+        int cnt[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) cnt[c] = 0;
+        for (int64_t j = st + lane; j < en; j += 64) {
+            const int l = cls[j];
+#pragma unroll
+            for (int c = 1; c < 16; ++c) cnt[c] += (l == c);
+        }
+        int best = 1, bv = 0;
+#pragma unroll
+        for (int c = 1; c < 16; ++c) {
+            int v = cnt[c];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (c == 1) bv = v;
+            else if (c < nof_labels && bv < v) { best = c; bv = v; }
+        }
+        for (int64_t j = st + lane; j < en; j += 64)
+            if (cls[j] == 0) out[j] = (int8_t)best;
+    }
+}
+
+DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int64_t n, int nof_labels,
+                                int min_mss_len, int xdrop_len, int8_t *d_labels_out, int64_t *d_nseg,
+                                void *d_work, int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(n >= 0 && n < (1ll << 31), "dgrp_mss_labels: n=%lld out of range (the reference indexes with int)", (long long)n);
+    DGRP_REQUIRE(nof_labels >= 2 && nof_labels <= 16, "dgrp_mss_labels: nof_labels must be in 2..16");
+    if (n == 0) {
+        if (d_nseg) DGRP_HIP(hipMemsetAsync(d_nseg, 0, sizeof(int64_t), stream));
+        return DGRP_OK;
+    }
+    DGRP_REQUIRE(d_scores && d_cls && d_labels_out && d_work, "dgrp_mss_labels: NULL pointer");
+    mss_layout l = mss_carve(d_work, n);
+    if (work_bytes < l.bytes) {
+        dgrp_set_error("dgrp_mss_labels: workspace %lld < %lld bytes", (long long)work_bytes, (long long)l.bytes);
+        return DGRP_ENOMEM;
+    }
+    // pymss.pyx:46-53 and mss.c:35 (int truncation of the threshold)
+    const double s0 = log(0.99 / (1.0 - 0.99));
+    const double xdrop = xdrop_len > 0 ? s0 * xdrop_len * 10.0 : -1;
+    const int min_sc = (int)(s0 * min_mss_len);
+    uint8_t *flags = (uint8_t *)l.segs_out;   // scratch until the compaction at the end
+
+    bool single = false;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        int64_t nunits = 1;
+        DGRP_HIP(hipMemsetAsync(l.grand, 0, 64, stream));
+        if (!single && xdrop > 0.0) {
+            DGRP_HIP(hipMemsetAsync(l.blk, 0, (l.nblk + 1) * 8, stream));
+            hipLaunchKernelGGL(mss_blockstat_kernel, dim3((unsigned)((l.nblk + 3) / 4)), dim3(256), 0, stream, d_scores, n,
+                               xdrop + 1.0, l.blk, flags);
+            DGRP_LAUNCH_CHECK();
+            hipLaunchKernelGGL(mss_boundary_kernel, dim3((unsigned)((l.nblk + 255) / 256)), dim3(256), 0, stream, flags,
+                               l.nblk, l.blk);
+            DGRP_LAUNCH_CHECK();
+            int rc = device_exclusive_scan(l.blk, l.blk, l.nblk, l.tiles, l.grand, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(mss_units_kernel, dim3((unsigned)((l.nblk + 255) / 256)), dim3(256), 0, stream, l.blk, flags,
+                               l.nblk, n, l.ustart, l.urun, l.grand);
+            DGRP_LAUNCH_CHECK();
+            uint64_t g = 0;
+            DGRP_HIP(hipMemcpyAsync(&g, l.grand, 8, hipMemcpyDeviceToHost, stream));
+            DGRP_HIP(hipStreamSynchronize(stream));
+            nunits = (int64_t)(g >> 32) + 1;
+        } else {
+            // one stretch: the plain sequential scan
+            int64_t h[2] = { 0, n };
+            DGRP_HIP(hipMemcpyAsync(l.ustart, h, 16, hipMemcpyHostToDevice, stream));
+            int64_t r[2] = { 0, 0 };
+            DGRP_HIP(hipMemcpyAsync(l.urun, r, 16, hipMemcpyHostToDevice, stream));
+            DGRP_HIP(hipStreamSynchronize(stream));
+        }
+        DGRP_HIP(hipMemsetAsync(l.exitL[0], 0, nunits * 8, stream));
+        DGRP_HIP(hipMemsetAsync(l.exitL[1], 0, nunits * 8, stream));
+        bool failed = false;
+        for (int pass = 0;; ++pass) {
+            // pass p reads the exits of pass p-1 from exitL[(p+1)&1] and writes exitL[p&1]
+            DGRP_HIP(hipMemsetAsync(l.grand + 1, 0, 8, stream));
+            hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)((nunits + 63) / 64)), dim3(64), 0, stream, d_scores,
+                               l.ustart, l.urun, nunits, l.exitL[(pass + 1) & 1], l.exitL[pass & 1], l.stack, l.segs,
+                               l.segcnt, min_sc, xdrop, l.grand, pass);
+            DGRP_LAUNCH_CHECK();
+            uint64_t g[3] = { 0, 0, 0 };
+            DGRP_HIP(hipMemcpyAsync(g, l.grand, 24, hipMemcpyDeviceToHost, stream));
+            DGRP_HIP(hipStreamSynchronize(stream));
+            if (g[2]) { failed = true; break; }
+            if (nunits == 1 || (pass > 0 && g[1] == 0)) break;
+            if (pass > nunits + 2) { failed = true; break; }
+        }
+        if (failed) {
+            if (single) { dgrp_set_error("dgrp_mss_labels: sequential scan reported an inconsistent state"); return DGRP_EHIP; }
+            single = true;
+            continue;
+        }
+        // kept segments -> one ordered list
+        int rc = device_exclusive_scan(l.segcnt, l.segcnt, nunits, l.tiles, l.grand + 3, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(mss_compact_kernel, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, stream, l.segs, l.urun,
+                           l.segcnt, l.grand + 3, nunits, l.segs_out);
+        DGRP_LAUNCH_CHECK();
+        break;
+    }
+    DGRP_HIP(hipMemcpyAsync(d_labels_out, d_cls, n, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(mss_vote_kernel, dim3(1024), dim3(256), 0, stream, l.segs_out, l.grand + 3, d_cls, nof_labels,
+                       d_labels_out);
+    DGRP_LAUNCH_CHECK();
+    if (d_nseg) DGRP_HIP(hipMemcpyAsync(d_nseg, l.grand + 3, 8, hipMemcpyDeviceToDevice, stream));
+    return DGRP_OK;
+}
+
+DGRP_EXPORT int dgrp_mss_segments_host(const void *d_work, int64_t work_bytes, int32_t *h_st_en, int64_t cap, int64_t *n_seg)
+{
+    DGRP_REQUIRE(d_work && n_seg, "dgrp_mss_segments_host: NULL pointer");
+    // the layout depends only on n, which the caller encodes through work_bytes = dgrp_mss_workspace_bytes(n):
+    // recover n by bisection (the carve is monotone in n)
+    int64_t lo = 0, hi = (1ll << 31) - 1;
+    while (lo < hi) {
+        int64_t mid = lo + (hi - lo + 1) / 2;
+        if (mss_carve(nullptr, mid).bytes <= work_bytes) lo = mid; else hi = mid - 1;
+    }
+    mss_layout l = mss_carve((void *)d_work, lo);
+    uint64_t cnt = 0;
+    DGRP_HIP(hipMemcpy(&cnt, l.grand + 3, 8, hipMemcpyDeviceToHost));
+    *n_seg = (int64_t)cnt;
+    const int64_t take = (int64_t)cnt < cap ? (int64_t)cnt : cap;
+    if (take > 0 && h_st_en) DGRP_HIP(hipMemcpy(h_st_en, l.segs_out, take * 8, hipMemcpyDeviceToHost));
+    return DGRP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// A11  deepgrp/sequence.pyx:38-53, :79-85 + the label > 0 filter of deepgrp/__main__.py:290.
+// get_segments never scans across the last element (length = size - 1), so runs live in
+// [0, n-1) and the last element is always a segment of its own.  A run's start and end are
+// flagged independently; the k-th start pairs with the k-th end.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool seg_is_start(const int8_t *lab, int64_t i, int64_t n)
+{
+    const int8_t v = lab[i];
+    return v != 0 && (i == 0 || i == n - 1 || lab[i - 1] != v);
+}
+__device__ __forceinline__ bool seg_is_end(const int8_t *lab, int64_t i, int64_t n)   // i = last element of a segment
+{
+    const int8_t v = lab[i];
+    return v != 0 && (i >= n - 2 || lab[i + 1] != v);
+}
+
+__global__ void __launch_bounds__(256) seg_count_kernel(const int8_t *__restrict__ lab, int64_t n, uint64_t *__restrict__ tilecnt)
+{
+    __shared__ uint64_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    uint64_t c = 0;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) c += ((uint64_t)seg_is_start(lab, i, n) << 32) + (uint64_t)seg_is_end(lab, i, n);
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ void __launch_bounds__(256) seg_emit_kernel(const int8_t *__restrict__ lab, int64_t n, int64_t offset, int32_t contig,
+                                                       const uint64_t *__restrict__ tileoff, dgrp_segment *__restrict__ rec, int64_t cap)
+{
+    __shared__ uint64_t lds[4];
+    // consecutive elements per thread so that the order of flags is the order of positions
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+    uint64_t f[8], s = 0;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + j;
+        f[j] = i < n ? ((uint64_t)seg_is_start(lab, i, n) << 32) + (uint64_t)seg_is_end(lab, i, n) : 0;
+        s += f[j];
+    }
+    uint64_t ex = block_exclusive_scan(s, nullptr, lds) + tileoff[blockIdx.x];
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + j;
+        if (f[j] >> 32) {
+            const int64_t k = (int64_t)(ex >> 32);
+            if (k < cap) { rec[k].start = i + offset; rec[k].label = lab[i]; rec[k].contig = contig; }
+        }
+        if (f[j] & 1) {
+            const int64_t k = (int64_t)(ex & 0xffffffffull);
+            if (k < cap) rec[k].end = i + 1 + offset;
+        }
+        ex += f[j];
+    }
+}
+
+__global__ void seg_total_kernel(const uint64_t *__restrict__ grand, int64_t *__restrict__ count)
+{
+    *count = (int64_t)(*grand >> 32);
+}
+
+DGRP_EXPORT int64_t dgrp_segments_workspace_bytes(int64_t n)
+{
+    if (n < 0) return 0;
+    return dgrp_align_up(((n + SCAN_TILE - 1) / SCAN_TILE + 2) * 8, 256) + 256;
+}
+
+DGRP_EXPORT int dgrp_segments(const int8_t *d_labels, int64_t n, int64_t offset, int32_t contig, dgrp_segment *d_records,
+                              int64_t cap, int64_t *d_count, void *d_work, int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(n >= 0 && n < (1ll << 31) && cap >= 0 && d_count, "dgrp_segments: bad arguments");
+    if (n == 0) {
+        DGRP_HIP(hipMemsetAsync(d_count, 0, sizeof(int64_t), stream));
+        return DGRP_OK;
+    }
+    DGRP_REQUIRE(d_labels && d_work && (cap == 0 || d_records), "dgrp_segments: NULL pointer");
+    if (work_bytes < dgrp_segments_workspace_bytes(n)) {
+        dgrp_set_error("dgrp_segments: workspace too small");
+        return DGRP_ENOMEM;
+    }
+    const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    uint64_t *tiles = (uint64_t *)d_work;
+    uint64_t *grand = tiles + ntiles + 1;
+    hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, n, tiles);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, tiles, ntiles, grand);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_emit_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, n, offset, contig, tiles,
+                       d_records, cap);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1), 0, stream, grand, d_count);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}

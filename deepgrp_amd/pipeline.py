@@ -1,0 +1,218 @@
+"""Device pipeline for one FASTA record: everything between the sequence bytes and
+the segment records stays in HBM.
+
+    bytes --encode--> class idx --GRU/attention + softmax + max-merge--> probs [N,C]
+          --scores--> (score f64, class i8) --MSS + vote--> labels i8 --RLE--> records
+
+This is what ``deepgrp predict`` (deepgrp/__main__.py:46-83, :280-292 of the
+reference) computes per record; `deepgrp_amd.prediction` / `.sequence` / `.mss`
+expose the individual reference functions on top of the same kernels.
+PyTorch is used only to own device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+SEGMENT_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("label", "<i4"), ("contig", "<i4")])
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("deepgrp_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
+                           "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceModel:
+    """The tensors ``tf.keras.models.load_model`` yields, packed into MFMA
+    fragments in HBM by ``dgrp_model_create``.  Mirrors the two Keras attributes the
+    reference reads: ``input_shape`` (__main__.py:270) and ``output_shape`` (:75)."""
+
+    def __init__(self, kernel, recurrent_kernel, bias, ff_kernel, ff_bias, scale=None, vecsize: int = 200):
+        require_gpu()
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        self.kernel, self.recurrent_kernel, self.bias = f32(kernel), f32(recurrent_kernel), f32(bias)
+        self.ff_kernel, self.ff_bias = f32(ff_kernel), f32(ff_bias)
+        self.scale = None if scale is None else f32(scale).reshape(-1)
+        self.units = int(self.recurrent_kernel.shape[0])
+        self.classes = int(self.ff_bias.shape[0])
+        self.vecsize = int(vecsize)
+        self.attention = self.scale is not None
+        u, c = self.units, self.classes
+        if self.kernel.shape != (5, 3 * u) or self.recurrent_kernel.shape != (u, 3 * u) or self.bias.shape != (2, 3 * u):
+            raise ValueError(f"GRU tensors have unexpected shapes {self.kernel.shape} {self.recurrent_kernel.shape} "
+                             f"{self.bias.shape}; expected reset_after GRU with 5 inputs")
+        if self.ff_kernel.shape != ((2 if self.attention else 1) * u, c):
+            raise ValueError(f"FF kernel shape {self.ff_kernel.shape} does not match units={u}, attention={self.attention}")
+        if self.attention and self.scale.shape != (u,):
+            raise ValueError("attention scale must have `units` entries")
+        h = C.c_void_p()
+        check(lib().dgrp_model_create(C.byref(h), self.vecsize, u, c, int(self.attention), _np_ptr(self.kernel),
+                                      _np_ptr(self.recurrent_kernel), _np_ptr(self.bias),
+                                      _np_ptr(self.scale) if self.attention else None, _np_ptr(self.ff_kernel),
+                                      _np_ptr(self.ff_bias)), "dgrp_model_create")
+        self.handle = h
+
+    input_shape = property(lambda self: (None, self.vecsize, 5))
+    output_shape = property(lambda self: (None, self.vecsize, self.classes))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().dgrp_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- model.predict_on_batch (prediction.py:106) ---------------------------------------
+    def forward_windows(self, d_idx: torch.Tensor, step: int, w0: int, nw: int) -> torch.Tensor:
+        """probs [nw, T, C] (device) of windows w0.. of a class-index tensor."""
+        probs = torch.empty((nw, self.vecsize, self.classes), dtype=torch.float32, device=d_idx.device)
+        wb = lib().dgrp_forward_workspace_bytes(self.handle, nw)
+        work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
+        check(lib().dgrp_forward_windows(self.handle, _ptr(d_idx), d_idx.numel(), step, w0, nw, _ptr(probs),
+                                         _ptr(work), work.numel(), stream_ptr()), "dgrp_forward_windows")
+        return probs
+
+    def predict_on_batch(self, batch) -> np.ndarray:
+        """Keras-style call on a one-hot batch [b, T, 5]; returns numpy float32 [b, T, C]."""
+        dev = require_gpu()
+        x = torch.as_tensor(np.asarray(batch) if not isinstance(batch, torch.Tensor) else batch)
+        if x.ndim != 3 or x.shape[1] != self.vecsize or x.shape[2] != 5:
+            raise ValueError(f"expected a batch of shape [b, {self.vecsize}, 5], got {tuple(x.shape)}")
+        idx = x.to(dev).argmax(dim=2).to(torch.uint8).reshape(-1).contiguous()
+        b = x.shape[0]
+        if b == 0:
+            return np.zeros((0, self.vecsize, self.classes), np.float32)
+        return self.forward_windows(idx, self.vecsize, 0, b).cpu().numpy()
+
+
+def upload_sequence(raw: bytes) -> Tuple[int, torch.Tensor]:
+    """A2 on the device: (startpos, class-index uint8 [N]).  Mirrors
+    one_hot_encode_dna_sequence's stripping of leading/trailing 'N' (sequence.pyx:27-30),
+    including the ValueError for an all-N record."""
+    dev = require_gpu()
+    st, kept = C.c_int64(0), C.c_int64(0)
+    host = np.frombuffer(raw, dtype=np.uint8)
+    check(lib().dgrp_strip_n(_np_ptr(host) if len(raw) else None, len(raw), C.byref(st), C.byref(kept)), "dgrp_strip_n")
+    if kept.value < 0:
+        raise ValueError("negative dimensions are not allowed")
+    n = kept.value
+    d_idx = torch.empty(n, dtype=torch.uint8, device=dev)
+    if n:
+        d_seq = torch.from_numpy(host[st.value:st.value + n].copy()).to(dev, non_blocking=False)
+        check(lib().dgrp_encode(_ptr(d_seq), n, _ptr(d_idx), stream_ptr()), "dgrp_encode")
+    return st.value, d_idx
+
+
+class ContigPipeline:
+    """Runs records through the device pipeline with the reference's CLI parameters."""
+
+    def __init__(self, model: DeviceModel, step_size: int = 50, batch_size: int = 256, min_mss_len: int = 50,
+                 xdrop_len: int = 50, use_mss: bool = True, chunk_windows: int = 1 << 20):
+        self.model = model
+        self.step = int(step_size)
+        self.batch = int(batch_size)
+        self.min_mss_len = int(min_mss_len)
+        self.xdrop_len = int(xdrop_len)
+        self.use_mss = bool(use_mss)
+        self.chunk_windows = int(chunk_windows)
+        if self.step < 1 or self.batch < 1:
+            raise ValueError("step_size and batch_size must be >= 1")
+
+    # A3-A6
+    def merged(self, d_idx: torch.Tensor) -> torch.Tensor:
+        m, L = self.model, lib()
+        n = d_idx.numel()
+        out = torch.zeros((n, m.classes), dtype=torch.float32, device=d_idx.device)      # np.zeros, prediction.py:103
+        nwin = L.dgrp_window_count(n, m.vecsize, self.step)
+        chunk = self.chunk_windows
+        if m.attention:
+            # keep the avg[t] spill of one launch below ~2 GiB
+            per = m.vecsize * (((m.units + 31) // 32) * 32 + m.classes) * 4
+            chunk = max(16, min(chunk, (2 << 30) // per // 16 * 16))
+        work = None
+        w0 = 0
+        while w0 < nwin:
+            nw = min(chunk, nwin - w0)
+            wb = L.dgrp_forward_workspace_bytes(m.handle, nw)
+            if work is None or work.numel() < wb:
+                work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
+            check(L.dgrp_forward_merge(m.handle, _ptr(d_idx), n, self.step, self.batch, w0, nw, _ptr(out),
+                                       _ptr(work), work.numel(), stream_ptr()), "dgrp_forward_merge")
+            w0 += nw
+        return out
+
+    # A7-A10 (or A8)
+    def labels(self, merged: torch.Tensor) -> torch.Tensor:
+        L = lib()
+        n, c = merged.shape
+        dev = merged.device
+        labels = torch.empty(n, dtype=torch.int8, device=dev)
+        if n == 0:
+            return labels
+        if self.use_mss:
+            scores = torch.empty(n, dtype=torch.float64, device=dev)
+            cls = torch.empty(n, dtype=torch.int8, device=dev)
+            check(L.dgrp_scores(_ptr(merged), n, c, _ptr(scores), _ptr(cls), stream_ptr()), "dgrp_scores")
+            wb = L.dgrp_mss_workspace_bytes(n)
+            work = torch.empty(wb, dtype=torch.uint8, device=dev)
+            check(L.dgrp_mss_labels(_ptr(scores), _ptr(cls), n, c, self.min_mss_len, self.xdrop_len, _ptr(labels),
+                                    None, _ptr(work), wb, stream_ptr()), "dgrp_mss_labels")
+        else:
+            work = torch.empty(4096, dtype=torch.uint8, device=dev)
+            check(L.dgrp_softmax_labels(_ptr(merged), n, c, None, _ptr(labels), _ptr(work), work.numel(),
+                                        stream_ptr()), "dgrp_softmax_labels")
+        return labels
+
+    # A11
+    def segments(self, labels: torch.Tensor, offset: int, contig: int = 0, cap: Optional[int] = None) -> np.ndarray:
+        L = lib()
+        n = labels.numel()
+        dev = labels.device
+        if n == 0:
+            return np.zeros(0, SEGMENT_DTYPE)
+        cap = cap if cap is not None else max(1024, n // 64)
+        wb = L.dgrp_segments_workspace_bytes(n)
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        while True:
+            rec = torch.empty(cap * SEGMENT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            check(L.dgrp_segments(_ptr(labels), n, offset, contig, _ptr(rec), cap, _ptr(count), _ptr(work), wb,
+                                  stream_ptr()), "dgrp_segments")
+            total = int(count.item())
+            if total <= cap:
+                break
+            cap = total                                     # rare: more segments than guessed, run again
+        host = rec[: total * SEGMENT_DTYPE.itemsize].cpu().numpy()
+        return host.view(SEGMENT_DTYPE).copy()
+
+    def run_idx(self, d_idx: torch.Tensor, startpos: int, contig: int = 0) -> np.ndarray:
+        return self.segments(self.labels(self.merged(d_idx)), startpos, contig)
+
+    def run(self, sequence, contig: int = 0) -> np.ndarray:
+        raw = sequence.encode("utf-8") if isinstance(sequence, str) else bytes(sequence)
+        startpos, d_idx = upload_sequence(raw)
+        return self.run_idx(d_idx, startpos, contig)

@@ -1,0 +1,148 @@
+/*
+ * deepgrp_hip.h -- C ABI of libdeepgrp_hip.so, the MI355X (gfx950) implementation of
+ * DeepGRP's prediction hot path.
+ *
+ * This is the drop-in boundary: plain C, raw pointers and sizes, no torch / Python
+ * types.  Every entry point names the reference interface it replaces (paths are
+ * relative to the upstream fhausmann/deepgrp repository).  The reference has two C
+ * symbols on this path (`_get_max`, deepgrp/maxcalc.h:3-4, and `mss_find_all`,
+ * deepgrp/_mss/mss.h:16-17) and otherwise crosses into compiled code through Cython
+ * (deepgrp/sequence.pyx, deepgrp/_mss/pymss.pyx) and TensorFlow
+ * (`model.predict_on_batch`, deepgrp/prediction.py:106).  INTEGRATION.md shows the
+ * ctypes stubs a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative DGRP_E* code on failure;
+ *     dgrp_last_error() returns a thread-local message for the last failure;
+ *   - pointers prefixed d_ are DEVICE pointers (HBM, allocated by the caller, e.g. by
+ *     torch.empty(..., device="cuda")); h_ are host pointers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work
+ *     is enqueued asynchronously on it unless a function says it synchronises;
+ *   - functions are re-entrant; a dgrp_model may be shared by threads that use
+ *     different streams and workspaces.
+ */
+#ifndef DEEPGRP_HIP_H_
+#define DEEPGRP_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGRP_OK 0
+#define DGRP_EINVAL (-1)   /* bad argument (shape, NULL pointer, unsupported size)   */
+#define DGRP_EHIP (-2)     /* a HIP runtime call or kernel launch failed              */
+#define DGRP_ENOMEM (-3)   /* caller-provided workspace / output capacity too small   */
+#define DGRP_ENODEV (-4)   /* no gfx950 device visible                                */
+
+#define DGRP_ABI_VERSION 1
+
+/* Segment record written by dgrp_segments(): one TSV row of deepgrp/__main__.py:288-292
+ * without the two name columns. */
+typedef struct dgrp_segment {
+    int64_t start;   /* 0-based, inclusive, in ORIGINAL (unstripped) record coordinates */
+    int64_t end;     /* exclusive                                                         */
+    int32_t label;   /* 1..C-1                                                            */
+    int32_t contig;  /* caller-defined tag copied from the call (record index)            */
+} dgrp_segment;
+
+typedef struct dgrp_model dgrp_model;   /* opaque: packed weights resident in HBM */
+
+int dgrp_abi_version(void);
+const char *dgrp_last_error(void);
+/* Name / CU count / HBM bytes of the current device (synchronous). */
+int dgrp_device_info(char *name, size_t name_cap, int *cu_count, int64_t *hbm_bytes);
+
+/* ---- A2: deepgrp.sequence.one_hot_encode_dna_sequence (deepgrp/sequence.pyx:19-36, :55-58)
+ * Host helper: number of leading exact 'N' bytes and kept length after dropping leading and
+ * trailing 'N' (negative for an all-N record: the reference raises ValueError there). */
+int dgrp_strip_n(const uint8_t *h_seq, int64_t len, int64_t *startpos, int64_t *kept);
+/* bytes -> class index 0..4 per base (A,a=0 C,c=1 G,g=2 T,t=3 else 4), the compact form every
+ * other kernel consumes. */
+int dgrp_encode(const uint8_t *d_seq, int64_t n, uint8_t *d_idx, void *stream);
+/* bytes -> int8 [5, n] C-order, exactly the array the reference function returns. */
+int dgrp_onehot(const uint8_t *d_seq, int64_t n, int8_t *d_onehot, void *stream);
+
+/* ---- A3: deepgrp.prediction.fetch_validation_batch (deepgrp/prediction.py:14-37)
+ * Number of windows len(range(0, n - T, s)). */
+int64_t dgrp_window_count(int64_t n, int64_t T, int64_t s);
+/* Materialise windows w0 .. w0+nw-1 as one-hot [nw, T, 5]; elem = 2 (fp16) or 4 (fp32, what the
+ * reference's generator yields).  Not used by the fused path; kept for API parity and as the
+ * HBM-roofline probe of the sliding encoder. */
+int dgrp_windows_onehot(const uint8_t *d_idx, int64_t n, int64_t T, int64_t s, int64_t w0,
+                        int64_t nw, int elem, void *d_out, void *stream);
+
+/* ---- A13: the tensors tf.keras.models.load_model extracts from the HDF5 file
+ * (deepgrp/__main__.py:264-270; layer graph deepgrp/model.py:293-336).  Host float32 arrays in
+ * Keras layout, gate columns z|r|h:  kernel [5,3u], recurrent [u,3u], bias [2,3u],
+ * scale [u] or NULL (no attention), ff_kernel [(attention?2u:u), C], ff_bias [C].
+ * Packs them into MFMA fragment order and uploads (synchronous). */
+int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *h_kernel,
+                      const float *h_recurrent, const float *h_bias, const float *h_scale,
+                      const float *h_ff_kernel, const float *h_ff_bias);
+int dgrp_model_destroy(dgrp_model *m);
+int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int *attention);
+
+/* ---- A4: model.predict_on_batch (deepgrp/prediction.py:106)
+ * Bytes of scratch HBM dgrp_forward_* needs for `nw` windows in one call. */
+int64_t dgrp_forward_workspace_bytes(const dgrp_model *m, int64_t nw);
+/* Class probabilities [nw, T, C] float32 of windows w0 .. w0+nw-1 of the index array. */
+int dgrp_forward_windows(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s,
+                         int64_t w0, int64_t nw, float *d_probs, void *d_work, int64_t work_bytes,
+                         void *stream);
+
+/* ---- A4+A5+A6 fused: deepgrp.prediction.predict (deepgrp/prediction.py:89-111) with
+ * get_max (deepgrp/sequence.pyx:65-76 -> deepgrp/maxcalc.c:10-24) folded into the classifier
+ * epilogue.  d_out is float32 [n, C] and MUST be zero-filled by the caller before the first call
+ * for a record (np.zeros, prediction.py:103).  Windows w0 .. w0+nw-1 are max-merged at the rows
+ * the reference would use for a user batch size `batch` INCLUDING its partial-last-batch
+ * offset, computed from the record's total window count. */
+int dgrp_forward_merge(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s,
+                       int64_t batch, int64_t w0, int64_t nw, float *d_out, void *d_work,
+                       int64_t work_bytes, void *stream);
+
+/* ---- A6 standalone: float *_get_max(float *output, float *inputs, size_t dim0, size_t dim1,
+ * size_t stride, size_t batchsize)  (deepgrp/maxcalc.h:3-4).  Same argument meaning; buffers on
+ * the device; out_rows bounds the writes (the reference has no bounds check). */
+int dgrp_get_max(float *d_output, int64_t out_rows, const float *d_inputs, int64_t dim0,
+                 int64_t dim1, int64_t stride, int64_t batchsize, void *stream);
+
+/* ---- A7: the score transform of deepgrp.prediction.apply_mss (deepgrp/prediction.py:51-57)
+ * probs float32 [n, C] -> scores float64 [n] and classes int8 [n] (argmax, first maximum). */
+int dgrp_scores(const float *d_probs, int64_t n, int C, double *d_scores, int8_t *d_cls,
+                void *stream);
+/* ---- A8: deepgrp.prediction.softmax + argmax (deepgrp/prediction.py:62-65,
+ * deepgrp/__main__.py:81-83): labels int8 [n]; d_softmax (float32 [n, C]) may be NULL. */
+int dgrp_softmax_labels(const float *d_probs, int64_t n, int C, float *d_softmax, int8_t *d_labels,
+                        void *d_work, int64_t work_bytes, void *stream);
+
+/* ---- A9+A10: deepgrp.mss.find_mss_labels (deepgrp/_mss/pymss.pyx:16-80) over
+ * msseg_t *mss_find_all(int n, const double *S, double min_sc, double xdrop, int *n_seg)
+ * (deepgrp/_mss/mss.h:16-17).  scores float64 [n], labels int8 [n] in; labels int8 [n] out (the
+ * argmax of the reference's one-hot rows).  n < 2^31 like the reference.  If d_nseg != NULL it
+ * receives the number of maximal segments kept (device int64).  Synchronises the stream (the
+ * fixed-point loop over independently scanned stretches reads a flag back). */
+int64_t dgrp_mss_workspace_bytes(int64_t n);
+int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int64_t n, int nof_labels,
+                    int min_mss_len, int xdrop_len, int8_t *d_labels_out, int64_t *d_nseg,
+                    void *d_work, int64_t work_bytes, void *stream);
+/* The segments themselves (st, en as int32 pairs, in order) for the last dgrp_mss_labels call on
+ * this workspace: copies up to cap pairs to the host, returns the count via *n_seg (synchronous). */
+int dgrp_mss_segments_host(const void *d_work, int64_t work_bytes, int32_t *h_st_en, int64_t cap,
+                           int64_t *n_seg);
+
+/* ---- A11: deepgrp.sequence.yield_segments / get_segments (deepgrp/sequence.pyx:38-53,
+ * :79-85) filtered by label > 0 (deepgrp/__main__.py:290): run-length extraction with the
+ * "last element is its own segment" behaviour.  Writes up to cap records (device) and the total
+ * count (device int64; may exceed cap, in which case only cap were written). */
+int64_t dgrp_segments_workspace_bytes(int64_t n);
+int dgrp_segments(const int8_t *d_labels, int64_t n, int64_t offset, int32_t contig,
+                  dgrp_segment *d_records, int64_t cap, int64_t *d_count, void *d_work,
+                  int64_t work_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPGRP_HIP_H_ */

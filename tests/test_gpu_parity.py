@@ -1,0 +1,335 @@
+"""Parity of the HIP path with the oracle and the golden vectors -- the tests proper.
+Everything here calls through the C ABI (deepgrp_amd._lib) on a real MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    return torch.device("cuda")
+
+
+@pytest.fixture(scope="module")
+def L():
+    from deepgrp_amd import _lib
+    return _lib.lib()
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _sp():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc):
+    from deepgrp_amd._lib import check
+    check(rc)
+
+
+# --------------------------------------------------------------------------------- A2 / A3 / A6
+def test_device_is_gfx950(L):
+    name = C.create_string_buffer(128)
+    cus, hbm = C.c_int(), C.c_int64()
+    _check(L.dgrp_device_info(name, 128, C.byref(cus), C.byref(hbm)))
+    assert b"gfx950" in name.value and cus.value >= 64 and hbm.value > (64 << 30)
+
+
+def test_encode_and_onehot_golden(L, dev, orc):
+    g = golden("onehot.npz")
+    for i in range(int(g["count"])):
+        raw = bytes(g[f"seq{i}"])
+        st, kept = C.c_int64(), C.c_int64()
+        host = np.frombuffer(raw, np.uint8)
+        _check(L.dgrp_strip_n(host.ctypes.data_as(C.c_void_p), len(raw), C.byref(st), C.byref(kept)))
+        assert st.value == int(g[f"start{i}"]) and kept.value == g[f"onehot{i}"].shape[1]
+        n = kept.value
+        if n == 0:
+            continue
+        d_seq = _t(host[st.value:st.value + n].copy(), dev)
+        d_idx = torch.empty(n, dtype=torch.uint8, device=dev)
+        d_oh = torch.empty((5, n), dtype=torch.int8, device=dev)
+        _check(L.dgrp_encode(d_seq.data_ptr(), n, d_idx.data_ptr(), _sp()))
+        _check(L.dgrp_onehot(d_seq.data_ptr(), n, d_oh.data_ptr(), _sp()))
+        np.testing.assert_array_equal(d_oh.cpu().numpy(), g[f"onehot{i}"])
+        np.testing.assert_array_equal(d_idx.cpu().numpy(), g[f"onehot{i}"].argmax(axis=0))
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 4099, 1 << 20])
+def test_encode_all_bytes_and_alignments(L, dev, orc, n):
+    rng = np.random.default_rng(n)
+    raw = rng.integers(0, 256, size=n + 3, dtype=np.uint8)
+    for shift in (0, 1, 3):
+        d_all = _t(raw, dev)
+        d_seq = d_all[shift:shift + n]
+        d_idx = torch.empty(n + 16, dtype=torch.uint8, device=dev)[shift:shift + n]
+        _check(L.dgrp_encode(d_seq.data_ptr(), n, d_idx.data_ptr(), _sp()))
+        np.testing.assert_array_equal(d_idx.cpu().numpy(), orc.encode_idx(bytes(raw[shift:shift + n])))
+        d_oh = torch.empty((5, n), dtype=torch.int8, device=dev)
+        _check(L.dgrp_onehot(d_seq.data_ptr(), n, d_oh.data_ptr(), _sp()))
+        want = np.zeros((5, n), np.int8)
+        want[orc.encode_idx(bytes(raw[shift:shift + n])), np.arange(n)] = 1
+        np.testing.assert_array_equal(d_oh.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("T,s,nw,w0", [(200, 50, 37, 0), (200, 50, 8, 5), (30, 4, 100, 3), (342, 50, 9, 1), (7, 1, 3, 0)])
+def test_windows_onehot(L, dev, orc, T, s, nw, w0):
+    rng = np.random.default_rng(T + nw)
+    n = (w0 + nw - 1) * s + T + 5
+    idx = rng.integers(0, 5, size=n).astype(np.uint8)
+    want = orc.windows_f32(idx, T, s, w0, nw)
+    d_idx = _t(idx, dev)
+    for elem, dt in ((4, torch.float32), (2, torch.float16)):
+        out = torch.full((nw, T, 5), 7.0, dtype=dt, device=dev)
+        _check(L.dgrp_windows_onehot(d_idx.data_ptr(), n, T, s, w0, nw, elem, out.data_ptr(), _sp()))
+        np.testing.assert_array_equal(out.float().cpu().numpy(), want)
+    assert L.dgrp_window_count(1000, 200, 50) == 16 and L.dgrp_window_count(200, 200, 50) == 0
+
+
+def test_get_max_golden(L, dev):
+    g = golden("get_max.npz")
+    for k in range(int(g["count"])):
+        out = _t(g[f"init{k}"], dev)
+        x = _t(g[f"in{k}"], dev)
+        b, d0, d1 = x.shape
+        _check(L.dgrp_get_max(out.data_ptr(), out.shape[0], x.data_ptr(), d0, d1, int(g[f"stride{k}"]), b, _sp()))
+        np.testing.assert_array_equal(out.cpu().numpy(), g[f"out{k}"])
+
+
+# --------------------------------------------------------------------------------- A4
+def _model(orc, u, T, attention, gain=1.0, seed=7, C_=5):
+    from deepgrp_amd.pipeline import DeviceModel
+    w = orc.Weights.random(u, C_, T, attention, seed=seed, gain=gain)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    return w, dm
+
+
+def _seq_idx(rng, n):
+    return rng.choice(5, size=n, p=[0.24, 0.25, 0.25, 0.24, 0.02]).astype(np.uint8)
+
+
+FORWARD_CASES = [
+    (128, 200, False, 1.0, 50, 70), (128, 200, False, 3.0, 50, 40), (128, 40, True, 1.5, 7, 33),
+    (60, 342, True, 1.0, 50, 20), (64, 30, False, 2.0, 4, 50), (32, 50, True, 1.0, 5, 17),
+    (96, 25, False, 1.0, 3, 35), (8, 20, True, 1.0, 2, 19), (100, 64, False, 1.5, 16, 16),
+]
+
+
+@pytest.mark.parametrize("u,T,attention,gain,s,nw", FORWARD_CASES)
+def test_forward_windows_vs_oracle(dev, orc, u, T, attention, gain, s, nw):
+    """Class probabilities within 1e-3 of the float64 statement (BASELINE north star); the
+    reference's own TF numerics are unavailable offline: parity unpinned beyond this."""
+    rng = np.random.default_rng(u * 1000 + T)
+    w, dm = _model(orc, u, T, attention, gain)
+    n = (nw + 2) * s + T
+    idx = _seq_idx(rng, n)
+    want = orc.nn_forward(idx, w, s, 2, nw, np.float64)
+    got = dm.forward_windows(_t(idx, dev), s, 2, nw).cpu().numpy()
+    err = np.abs(got - want).max()
+    print(f"u={u} T={T} att={attention} gain={gain}: max |dp| = {err:.2e}")
+    assert err < 1e-3
+    np.testing.assert_allclose(got.sum(axis=2), 1.0, atol=1e-5)
+    dm.close()
+
+
+def test_predict_on_batch_keras_style(dev, orc):
+    rng = np.random.default_rng(3)
+    w, dm = _model(orc, 32, 24, False, 1.0)
+    idx = _seq_idx(rng, 24 * 6)
+    batch = np.eye(5, dtype=np.float32)[idx].reshape(6, 24, 5)
+    got = dm.predict_on_batch(batch)
+    want = orc.nn_forward(idx, w, 24, 0, 6, np.float64)
+    assert got.shape == (6, 24, 5) and np.abs(got - want).max() < 1e-3
+    dm.close()
+
+
+@pytest.mark.parametrize("N,T,s,B,u,attention", [(1050, 200, 50, 4, 128, False), (1001, 200, 50, 5, 64, False),
+                                                  (5000, 200, 50, 7, 128, False), (5000, 200, 50, 256, 128, False),
+                                                  (777, 30, 4, 10, 32, True), (200, 200, 50, 4, 32, False),
+                                                  (201, 200, 50, 4, 32, False), (3000, 100, 300, 3, 32, False)])
+def test_forward_merge_placement_exact(dev, orc, L, N, T, s, B, u, attention):
+    """The fused max-merge must equal get_max applied batch by batch to the SAME probabilities
+    (bit for bit), incl. the partial-last-batch offset, and be within 1e-3 of the
+    float64 oracle."""
+    from deepgrp_amd.pipeline import ContigPipeline
+    rng = np.random.default_rng(N + B)
+    w, dm = _model(orc, u, T, attention, 1.5)
+    idx = _seq_idx(rng, N)
+    d_idx = _t(idx, dev)
+    nwin = orc.window_count(N, T, s)
+    assert nwin == L.dgrp_window_count(N, T, s)
+    for chunk in (1 << 20, 48):
+        merged = ContigPipeline(dm, s, B, chunk_windows=chunk).merged(d_idx).cpu().numpy()
+        probs = dm.forward_windows(d_idx, s, 0, nwin).cpu().numpy() if nwin else np.zeros((0, T, 5), np.float32)
+        np.testing.assert_array_equal(merged, orc.merge_all(probs, N, s, B))
+        np.testing.assert_array_equal(merged, orc.predict_merged(idx, lambda a, b: probs[a:a + b], T, 5, s, B))
+    if nwin:
+        ref = orc.merge_all(orc.nn_forward(idx, w, s, 0, nwin, np.float64).astype(np.float32), N, s, B)
+        assert np.abs(merged - ref).max() < 1e-3
+    dm.close()
+
+
+# --------------------------------------------------------------------------------- A7 - A11
+def _labels_gpu(L, dev, probs, ml, xd, use_mss=True):
+    n, c = probs.shape
+    d_p = _t(probs, dev)
+    sc = torch.empty(n, dtype=torch.float64, device=dev)
+    cl = torch.empty(n, dtype=torch.int8, device=dev)
+    lab = torch.empty(n, dtype=torch.int8, device=dev)
+    _check(L.dgrp_scores(d_p.data_ptr(), n, c, sc.data_ptr(), cl.data_ptr(), _sp()))
+    wb = L.dgrp_mss_workspace_bytes(n)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    nseg = torch.zeros(1, dtype=torch.int64, device=dev)
+    _check(L.dgrp_mss_labels(sc.data_ptr(), cl.data_ptr(), n, c, ml, xd, lab.data_ptr(), nseg.data_ptr(),
+                             work.data_ptr(), wb, _sp()))
+    return sc.cpu().numpy(), cl.cpu().numpy(), lab.cpu().numpy(), int(nseg.item()), work
+
+
+def test_scores_mss_rows_golden(L, dev, orc):
+    """prediction.py:51-59 -> pymss.pyx -> sequence.pyx:79-85 against the reference's outputs."""
+    from deepgrp_amd.pipeline import ContigPipeline, SEGMENT_DTYPE
+    g = golden("probs_to_rows.npz")
+    for k in range(int(g["count"])):
+        probs = g[f"probs{k}"]
+        ml, xd, off = (int(v) for v in g[f"par{k}"])
+        sc, cl, lab, nseg, work = _labels_gpu(L, dev, probs, ml, xd)
+        np.testing.assert_array_equal(cl, g[f"cls{k}"])
+        np.testing.assert_array_equal(sc.view(np.int64), g[f"scores{k}"].view(np.int64))
+        np.testing.assert_array_equal(lab, g[f"labels{k}"], err_msg=f"case {k}")
+        _, segs = orc.find_mss_labels(g[f"scores{k}"], g[f"cls{k}"], probs.shape[1], ml, xd, return_segments=True)
+        assert nseg == len(segs)
+        buf = np.zeros((max(nseg, 1), 2), np.int32)
+        cnt = C.c_int64()
+        _check(L.dgrp_mss_segments_host(work.data_ptr(), work.numel(), buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
+        assert cnt.value == nseg
+        np.testing.assert_array_equal(buf[:nseg], np.array([(a, b) for a, b, _ in segs], np.int32).reshape(-1, 2))
+        rows = ContigPipeline.segments(None, _t(lab, dev), off, 3)
+        assert rows.dtype == SEGMENT_DTYPE and (rows["contig"] == 3).all()
+        np.testing.assert_array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1), g[f"rows{k}"])
+
+
+def test_mss_raw_golden(L, dev):
+    g = golden("mss_raw.npz")
+    for k in range(int(g["count"])):
+        nof, ml, xd = (int(v) for v in g[f"p{k}"])
+        s, l = g[f"s{k}"], g[f"l{k}"]
+        n = len(s)
+        d_s, d_l = _t(s, dev), _t(l.astype(np.int8), dev)
+        lab = torch.empty(n, dtype=torch.int8, device=dev)
+        wb = L.dgrp_mss_workspace_bytes(n)
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        _check(L.dgrp_mss_labels(d_s.data_ptr(), d_l.data_ptr(), n, nof, ml, xd, lab.data_ptr(), None,
+                                 work.data_ptr(), wb, _sp()))
+        np.testing.assert_array_equal(lab.cpu().numpy(), g[f"o{k}"], err_msg=f"case {k}")
+
+
+def test_mss_kat(L, dev):
+    """tests/test_mss.py:10-24 of the reference through the GPU path."""
+    g = golden("mss_kat.npz")
+    for ml in (0, 3, 10):
+        for xd in (-1, 0, 10):
+            d_s, d_l = _t(g["scores"], dev), _t(g["labels"].astype(np.int8), dev)
+            lab = torch.empty(14, dtype=torch.int8, device=dev)
+            wb = L.dgrp_mss_workspace_bytes(14)
+            work = torch.empty(wb, dtype=torch.uint8, device=dev)
+            _check(L.dgrp_mss_labels(d_s.data_ptr(), d_l.data_ptr(), 14, 3, ml, xd, lab.data_ptr(), None,
+                                     work.data_ptr(), wb, _sp()))
+            np.testing.assert_array_equal(lab.cpu().numpy(), g[f"out_{ml}_{xd}"])
+
+
+@pytest.mark.parametrize("n,style", [(300000, "runs"), (300000, "noise"), (1 << 21, "runs"), (70000, "background")])
+def test_mss_stretch_parallel_vs_oracle(L, dev, orc, n, style):
+    """Sizes where the sequence is cut into many independently scanned stretches: labels and
+    segment list must equal the sequential oracle exactly."""
+    rng = np.random.default_rng(n)
+    if style == "noise":
+        probs = rng.dirichlet(np.full(5, 0.3), size=n).astype(np.float32)
+    else:
+        lab = np.zeros(n, np.int64)
+        i = 0
+        while i < n:
+            ln = int(rng.geometric(1 / 400.0))
+            lab[i:i + ln] = 0 if (rng.random() < (0.97 if style == "background" else 0.6)) else int(rng.integers(1, 5))
+            i += ln
+        p = rng.dirichlet(np.full(5, 0.25), size=n).astype(np.float32)
+        strength = (rng.beta(8, 1.0, size=n) * 0.985).astype(np.float32)
+        probs = ((1 - strength)[:, None] * p + strength[:, None] * np.eye(5, dtype=np.float32)[lab]).astype(np.float32)
+        probs[n - 41:] = 0
+    sc_o, cl_o = orc.scores(probs)
+    sc, cl, lab_g, nseg, work = _labels_gpu(L, dev, probs, 50, 50)
+    np.testing.assert_array_equal(sc.view(np.int64), sc_o.view(np.int64))
+    np.testing.assert_array_equal(cl, cl_o)
+    lab_o, segs = orc.find_mss_labels(sc_o, cl_o, 5, 50, 50, return_segments=True)
+    assert nseg == len(segs)
+    np.testing.assert_array_equal(lab_g, lab_o)
+
+
+def test_softmax_path_golden(L, dev):
+    g = golden("softmax.npz")
+    probs = g["probs"]
+    n, c = probs.shape
+    d_p = _t(probs, dev)
+    sm = torch.empty((n, c), dtype=torch.float32, device=dev)
+    lab = torch.empty(n, dtype=torch.int8, device=dev)
+    work = torch.empty(4096, dtype=torch.uint8, device=dev)
+    _check(L.dgrp_softmax_labels(d_p.data_ptr(), n, c, sm.data_ptr(), lab.data_ptr(), work.data_ptr(), 4096, _sp()))
+    np.testing.assert_array_equal(sm.cpu().numpy().view(np.int32), g["softmax"].view(np.int32))
+    np.testing.assert_array_equal(lab.cpu().numpy(), g["labels"])
+
+
+def test_segments_golden(L, dev):
+    from deepgrp_amd.pipeline import ContigPipeline
+    g = golden("segments.npz")
+    for k in range(int(g["count"])):
+        lab = g[f"lab{k}"]
+        allseg = g[f"all{k}"]
+        rows = ContigPipeline.segments(None, _t(lab.astype(np.int8), dev), 5, 0, cap=4)
+        want = allseg[allseg[:, 2] > 0]
+        np.testing.assert_array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3), want)
+
+
+def test_segments_large_random_vs_oracle(L, dev, orc):
+    from deepgrp_amd.pipeline import ContigPipeline
+    rng = np.random.default_rng(9)
+    for n, p0 in ((1 << 20, 0.5), (123457, 0.0), (5000, 0.9)):
+        lab = np.zeros(n, np.int8)
+        i = 0
+        while i < n:
+            ln = int(rng.geometric(0.05))
+            lab[i:i + ln] = 0 if rng.random() < p0 else rng.integers(1, 5)
+            i += ln
+        rows = ContigPipeline.segments(None, _t(lab, dev), 17, 1)
+        want = orc.segments(lab.astype(np.int64), 17)
+        np.testing.assert_array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3), want)
+
+
+# --------------------------------------------------------------------------------- whole path
+@pytest.mark.parametrize("u,T,attention,use_mss", [(128, 200, False, True), (60, 342, True, True), (32, 100, False, False)])
+def test_pipeline_end_to_end(dev, orc, u, T, attention, use_mss):
+    """FASTA record -> rows.  Post-processing is exact given the probabilities: the oracle is
+    driven with the GPU's own window probabilities, so rows must be identical."""
+    from deepgrp_amd.pipeline import ContigPipeline, upload_sequence
+    rng = np.random.default_rng(u)
+    w, dm = _model(orc, u, T, attention, 3.0)
+    body = "".join(rng.choice(list("ACGT"), size=30011))
+    seq = "NNNNNNN" + body[:9000] + "N" * 700 + body[9000:] + "NNN"
+    pipe = ContigPipeline(dm, 50, 256, 50, 50, use_mss)
+    rows = pipe.run(seq, contig=2)
+    st, d_idx = upload_sequence(seq.encode())
+    nwin = orc.window_count(d_idx.numel(), T, 50)
+    probs = dm.forward_windows(d_idx, 50, 0, nwin).cpu().numpy()
+    want = orc.predict_contig(seq, lambda idx: (lambda a, b: probs[a:a + b]), T, 5, 50, 256, 50, 50, use_mss)
+    np.testing.assert_array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3), want)
+    assert st == 7
+    dm.close()
