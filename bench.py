@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mbp/s predicted at window=200 stride=50, 5 classes (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mbp M]
+
+A "step" is one pass of the whole hot path (class-index encode -> GRU + dense + softmax +
+max-merge -> score transform -> MSS + vote -> segment extraction -> record gather) over one
+synthetic chromosome per GPU whose bytes are already resident in HBM.  N > 1 is launched by
+torchrun, one rank per GPU; records shard by contig (weak scaling, no data-path collective),
+the only exchange is the gather of segment records to rank 0 over RCCL.
+
+Prints ONE JSON line (rank 0) carrying `roofline` for the dominant kernel (the fused GRU
+kernel, MFMA-bound, timed live with HIP events on its stream) and `cpu_baseline` (the CPU
+restatement of the same path, oracle/, timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from deepgrp_amd import synthetic                                  # noqa: E402
+from deepgrp_amd.distributed import gather_records                 # noqa: E402
+from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence   # noqa: E402
+
+T, STEP, UNITS, CLASSES, BATCH, MIN_MSS, XDROP = 200, 50, 128, 5, 256, 50, 50
+MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md, chip-level parameters
+FLOP_PER_WINDOW = 12 * UNITS * UNITS * T + 2 * UNITS * CLASSES * T
+
+
+def cpu_baseline(weights, sample_bp: int):
+    """The oracle (CPU restatement, all host threads) on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    seq = synthetic.synthetic_chromosome(sample_bp, contig=0, flank=1000).decode()
+    w = orc.Weights(weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
+                    weights["ff_bias"], weights["scale"], T)
+    threads = orc.lib().orc_max_threads()
+
+    def factory(idx):
+        return lambda w0, nw: orc.nn_forward(idx, w, STEP, w0, nw, np.float32, threads)
+
+    t0 = time.perf_counter()
+    rows = orc.predict_contig(seq, factory, T, CLASSES, STEP, BATCH, MIN_MSS, XDROP, True)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_bp / dt / 1e6, 5), "unit": "Mbp/s", "cores": int(threads), "kind": "port",
+            "sample": f"{sample_bp} bp synthetic contig, full path (oracle/dgrp_oracle.c, float32, OpenMP over windows), "
+                      f"{dt:.1f} s, {len(rows)} rows"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mbp", type=float, default=50.0, help="chromosome size per GPU in Mbp (configs[1] = 50)")
+    ap.add_argument("--gain", type=float, default=3.0, help="weight scale of the synthetic model (3 = structured set)")
+    ap.add_argument("--bias0", type=float, default=0.0, help="added to the background class's dense bias")
+    ap.add_argument("--cpu-sample-bp", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    weights = synthetic.synthetic_weights(UNITS, CLASSES, attention=False, seed=7, gain=args.gain)
+    weights["ff_bias"][0] += args.bias0
+    model = DeviceModel(weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
+                        weights["ff_bias"], weights["scale"], vecsize=T)
+    pipe = ContigPipeline(model, STEP, BATCH, MIN_MSS, XDROP, use_mss=True)
+    n_bases = int(args.mbp * 1e6)
+    raw = synthetic.synthetic_chromosome(n_bases, contig=rank)
+    startpos, d_idx = upload_sequence(raw)                 # also validates the encoder once
+    # the resident input of a step: the stripped sequence bytes in HBM
+    d_seq = torch.from_numpy(np.frombuffer(raw, np.uint8)[startpos:startpos + d_idx.numel()].copy()).to(dev)
+    n = d_seq.numel()
+    from deepgrp_amd._lib import check, lib
+    from deepgrp_amd.pipeline import stream_ptr
+
+    def step():
+        check(lib().dgrp_encode(d_seq.data_ptr(), n, d_idx.data_ptr(), stream_ptr()), "dgrp_encode")
+        rows = pipe.run_idx(d_idx, startpos, contig=rank)
+        return gather_records(rows, dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    pipe.event_log = []
+    t0 = time.perf_counter()
+    nrows = 0
+    for _ in range(args.steps):
+        nrows = len(step())
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    # dominant kernel: the fused GRU kernel (one launch per dgrp_forward_merge for this model)
+    kern_ms = [a.elapsed_time(b) for a, b, _ in pipe.event_log]
+    kern_windows = [w for _, _, w in pipe.event_log]
+    avg_ms = float(np.mean(kern_ms))
+    achieved = float(np.mean(kern_windows)) * FLOP_PER_WINDOW / (avg_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        value = n_bases * world * args.steps / dt / 1e6
+        out = {
+            "metric": "Mbp/sec predicted (whole node) at window=200 stride=50, 5-class",
+            "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16 MFMA operands / f32 accumulate+state (GRU); f32/f64/int post-processing",
+            "data": "synthetic",
+            "config": {"workload": f"{args.mbp:g} Mbp synthetic chromosome per GPU (BASELINE configs[1]), "
+                                   f"window={T} stride={STEP} hidden={UNITS} {CLASSES}-class, batch_size={BATCH}, "
+                                   f"MSS min_len={MIN_MSS} xdrop={XDROP}, random-init weights gain={args.gain:g}",
+                       "rows_out": int(nrows), "parallelism": f"contig-sharded x{world}"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "gru_fused_kernel<4>", "avg_launch_ms": round(avg_ms, 3),
+                         "windows_per_launch": int(np.mean(kern_windows)), "launches_timed": len(kern_ms)},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample_bp)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,9 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `make -C deepgrp_amd/csrc` (hipcc, gfx950) "
                 "or `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+        # PyTorch-ROCm ships its own libamdhip64; it must be in the process BEFORE this library is
+        # loaded so that both bind to the same HIP runtime (streams and device pointers are shared).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             f = getattr(L, name)

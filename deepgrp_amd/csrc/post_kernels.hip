@@ -240,34 +240,51 @@ static int device_exclusive_scan(const uint64_t *in, uint64_t *out, int64_t n, u
 }
 
 // ------------------------------------------------------------------------------------------
-// A10  mss_find_all (deepgrp/_mss/mss.c:50-101) -- "stretch-parallel, fixed-point" form.
+// A10  mss_find_all (deepgrp/_mss/mss.c:50-101) -- "stretch-parallel, fixed-point, wave-chunked" form.
 //
-// The algorithm is a left fold in double precision (L += S[i]); it cannot be re-associated
-// without changing roundings.  What CAN be done exactly: an x-drop reset (mss.c:89-92) returns the
-// scan to a history-free state (stack empty, max = -1e30), and a block of 64 consecutive
-// non-positive scores whose sum is below -(xdrop + 1) forces such a reset inside it whenever the
-// state was not already history-free (the running max is >= L on entry and never grows inside the
-// block).  So right after such a block the only thing the scan remembers is the scalar L.  The
-// sequence is cut into "stretches" at those points, every stretch is scanned by one thread with
-// the reference's exact arithmetic starting from a guessed L, and the guesses are iterated
-// (stretch k starts from the L stretch k-1 ended with in the previous pass) until no stretch's
-// final L changes.  By induction over k the fixed point is exactly the sequential result.  The
-// x-drop reset makes a stretch's final L independent of its initial L whenever it contains a
-// positive score, so two passes are the norm; the worst case (no qualifying block anywhere) is
-// one stretch = the sequential scan on one lane.
+// The algorithm is a left fold in double precision (L += S[i]); re-associating it changes
+// roundings.  Three exact observations make it parallel without changing a single bit:
+//
+//  (1) Cutting.  An x-drop reset (mss.c:89-92) returns the scan to a history-free state (stack
+//      empty, max = -1e30).  A stretch of non-positive scores whose sum is below -(xdrop + 1)
+//      forces such a reset inside it whenever the state was not already history-free (the running
+//      max is >= L on entry and cannot grow inside the stretch).  Right after such a stretch the
+//      scan remembers only the scalar L.  The sequence is cut into "stretches" at those points.
+//  (2) Fixed point.  Every stretch is scanned (by one wave) with the reference's own arithmetic
+//      from a guessed entry L; stretch k's guess in pass p is stretch k-1's final L of pass p-1.
+//      When a pass changes no final L, induction over k shows every stretch started from the true
+//      L, i.e. the result IS the sequential result.  A reset makes the final L independent of the
+//      entry L, so two passes are the norm; one stretch (= the sequential scan) is the worst case.
+//  (3) Chunks.  Inside a stretch the wave takes 64 scores at a time.  If every score of the chunk
+//      and L are integer multiples of 2^-Q and |L| + sum|s| < 2^(53-Q), every partial sum the
+//      reference forms is exactly representable, so its left fold equals the exact prefix sum and
+//      a wave prefix scan reproduces it bit for bit ("certificate").  Positive runs, x-drop
+//      triggers and run ends are then found with ballots; only the per-run stack work stays
+//      serial.  Whole all-non-positive 64-blocks are skipped 64 at a time in the history-free
+//      state under the same certificate.  A chunk whose certificate fails is folded element by
+//      element.
 // ------------------------------------------------------------------------------------------
 struct mss_cand { int32_t st, en; double L, R; int32_t pre, pad; };   // mss.c:24-28
 
+#define MSS_LCAP 160          // candidates kept in LDS per wave; deeper ones spill to HBM
+#define MSS_NEG (-1e30)       // NEG_INF, mss.c:33
+#define MSS_QNONE (-4096)
+#define MSS_QBAD 4096
+
 struct mss_layout {            // carve of the caller's workspace
     int64_t nblk;
-    uint64_t *blk;             // [nblk+1] per-64-block packed (boundary flag << 32 | positive-run starts), then scanned
+    uint64_t *blk;             // [nblk+1] per-64-block (boundary flag << 32 | positive-run starts), then scanned
+    double *blk_sum;           // [nblk] sum of the block's scores
+    double *blk_abs;           // [nblk] sum of |score|
+    int32_t *blk_q;            // [nblk] smallest Q with every score a multiple of 2^-Q
+    uint8_t *flags;            // [nblk] bit0: contains a positive score
     uint64_t *tiles;           // scan scratch
-    uint64_t *grand;           // [4]: [0] scan total, [1] changed flag, [2] error flag, [3] total kept segments
+    uint64_t *grand;           // [8]: [0] scan total, [1] changed flag, [2] error flag, [3] total kept segments
     int64_t *ustart;           // [nunits+1] stretch starts
     int64_t *urun;             // [nunits+1] first stack/segment slot of each stretch
     double *exitL[2];          // [nunits] final L of each stretch, ping-pong
     uint64_t *segcnt;          // [nunits+1] kept segments per stretch, then scanned
-    mss_cand *stack;           // [nruns]
+    mss_cand *stack;           // [nruns] overflow stack slots
     int32_t *segs;             // [nruns][2] kept segments in stretch-local slots
     int32_t *segs_out;         // [nruns][2] compacted
     int64_t bytes;
@@ -281,6 +298,10 @@ static mss_layout mss_carve(void *work, int64_t n)
     l.nblk = (n + 63) / 64;
     const int64_t maxunits = l.nblk + 1, maxruns = n / 2 + 2;
     l.blk = (uint64_t *)take((l.nblk + 1) * 8);
+    l.blk_sum = (double *)take(l.nblk * 8);
+    l.blk_abs = (double *)take(l.nblk * 8);
+    l.blk_q = (int32_t *)take(l.nblk * 4);
+    l.flags = (uint8_t *)take(l.nblk + 64);
     l.tiles = (uint64_t *)take(((maxunits + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 8);
     l.grand = (uint64_t *)take(64);
     l.ustart = (int64_t *)take((maxunits + 1) * 8);
@@ -301,13 +322,48 @@ DGRP_EXPORT int64_t dgrp_mss_workspace_bytes(int64_t n)
     return mss_carve(nullptr, n).bytes;
 }
 
-// One wave per 64-block: does the block force an x-drop reset (see above)?  How many positive
-// runs START in it?  Packed as (boundary candidate << 32) | run starts; a candidate becomes a
-// stretch boundary only if the NEXT block contains a positive score (a long background stretch
-// stays with the stretch before it instead of being cut into one trivial stretch per block, which
-// would make the fixed-point iteration crawl one block per pass).
-__global__ void __launch_bounds__(256) mss_blockstat_kernel(const double *__restrict__ S, int64_t n, double thr,
-                                                            uint64_t *__restrict__ blk, uint8_t *__restrict__ flags)
+// smallest Q such that x is an integer multiple of 2^-Q
+__device__ __forceinline__ int quantum_exp(double x)
+{
+    const uint64_t b = (uint64_t)__double_as_longlong(x) & 0x7fffffffffffffffull;
+    if (b == 0) return MSS_QNONE;
+    const int e = (int)(b >> 52);
+    if (e == 0 || e == 0x7ff) return MSS_QBAD;                 // subnormal / inf / nan: never certified
+    const uint64_t m = b & 0x000fffffffffffffull;
+    const int tz = m ? __builtin_ctzll(m) : 52;
+    return -((e - 1023) - 52 + tz);
+}
+
+// all partial sums of {L, s...} exactly representable?
+__device__ __forceinline__ bool mss_certified(double L, double sumabs, int q_scores)
+{
+    const int qL = quantum_exp(L);
+    const int Q = qL > q_scores ? qL : q_scores;
+    if (Q >= MSS_QBAD) return false;
+    const int ex = 53 - Q;
+    if (ex > 1000) return true;
+    if (ex < -1000) return false;
+    return (fabs(L) + sumabs) * 1.0000001 < ldexp(1.0, ex);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int w = __shfl_xor(v, o); v = w > v ? w : v; }
+    return v;
+}
+
+// One wave per 64-block: statistics used for cutting (1) and skipping (3).
+__global__ void __launch_bounds__(256) mss_blockstat_kernel(const double *__restrict__ S, int64_t n,
+                                                            uint64_t *__restrict__ blk, double *__restrict__ blk_sum,
+                                                            double *__restrict__ blk_abs, int32_t *__restrict__ blk_q,
+                                                            uint8_t *__restrict__ flags)
 {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -318,29 +374,46 @@ __global__ void __launch_bounds__(256) mss_blockstat_kernel(const double *__rest
     const bool prevpos = i > 0 && i < n && S[i - 1] > 0;
     const unsigned long long mpos = __ballot(pos);
     const unsigned long long mstart = __ballot(pos && !prevpos);
-    double sum = s;
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const double sum = wave_sum(s), sabs = wave_sum(fabs(s));
+    const int q = wave_max(quantum_exp(s));
     if (lane == 0) {
-        const bool full = b * 64 + 64 <= n;
-        const bool qual = full && mpos == 0ull && thr > 0.0 && sum < -thr;
-        flags[b] = (uint8_t)((qual ? 1 : 0) | (mpos != 0ull ? 2 : 0));
+        flags[b] = (uint8_t)(mpos != 0ull ? 1 : 0);
         blk[b] = (uint64_t)__popcll(mstart);
+        blk_sum[b] = sum;
+        blk_abs[b] = sabs;
+        blk_q[b] = q;
     }
 }
 
-__global__ void __launch_bounds__(256) mss_boundary_kernel(const uint8_t *__restrict__ flags, int64_t nblk,
-                                                           uint64_t *__restrict__ blk)
+// A cut goes after block b when b ends a chain of all-non-positive blocks, the next block has a
+// positive score, and the last (up to 16) blocks of the chain sum below -thr (forced reset).
+__device__ __forceinline__ bool mss_is_boundary(const uint8_t *flags, const double *blk_sum, int64_t b, int64_t nblk,
+                                                int64_t n, double thr)
+{
+    if (!(thr > 0.0) || b + 1 >= nblk || (flags[b] & 1) || !(flags[b + 1] & 1)) return false;
+    if (b * 64 + 64 > n) return false;
+    double cum = 0.0;
+    for (int64_t j = b; j >= 0 && j > b - 16; --j) {
+        if (flags[j] & 1) break;
+        cum += blk_sum[j];
+        if (cum < -thr) return true;
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(256) mss_boundary_kernel(const uint8_t *__restrict__ flags, const double *__restrict__ blk_sum,
+                                                           int64_t nblk, int64_t n, double thr, uint64_t *__restrict__ blk)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nblk) return;
-    const bool boundary = (flags[b] & 1) && b + 1 < nblk && (flags[b + 1] & 2);
-    if (boundary) blk[b] |= 1ull << 32;
+    if (mss_is_boundary(flags, blk_sum, b, nblk, n, thr)) blk[b] |= 1ull << 32;
 }
 
 // after the exclusive scan of blk: block b's entry holds (#boundaries before b, #run starts before b)
 __global__ void __launch_bounds__(256) mss_units_kernel(const uint64_t *__restrict__ blk, const uint8_t *__restrict__ flags,
-                                                        int64_t nblk, int64_t n, int64_t *__restrict__ ustart,
-                                                        int64_t *__restrict__ urun, const uint64_t *__restrict__ grand)
+                                                        const double *__restrict__ blk_sum, int64_t nblk, int64_t n, double thr,
+                                                        int64_t *__restrict__ ustart, int64_t *__restrict__ urun,
+                                                        const uint64_t *__restrict__ grand)
 {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) {
@@ -351,93 +424,194 @@ __global__ void __launch_bounds__(256) mss_units_kernel(const uint64_t *__restri
         urun[nunits] = (int64_t)(grand[0] & 0xffffffffull);
     }
     if (b >= nblk) return;
-    const bool boundary = (flags[b] & 1) && b + 1 < nblk && (flags[b + 1] & 2);
-    if (boundary) {
-        const int64_t k = (int64_t)(blk[b] >> 32) + 1;          // this boundary opens stretch k
+    if (mss_is_boundary(flags, blk_sum, b, nblk, n, thr)) {
+        const int64_t k = (int64_t)(blk[b] >> 32) + 1;          // this cut opens stretch k
         ustart[k] = (b + 1) * 64;
-        // run starts before block b+1 = starts before b + starts in b (none: b is all non-positive)
-        urun[k] = (int64_t)(blk[b] & 0xffffffffull);
+        urun[k] = (int64_t)(blk[b] & 0xffffffffull);            // block b itself starts no run
     }
 }
 
-// One thread per stretch, the reference loop verbatim in double precision.
+// One wave per stretch.
 __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__ S, const int64_t *__restrict__ ustart,
                                                       const int64_t *__restrict__ urun, int64_t nunits,
                                                       const double *__restrict__ exit_prev, double *__restrict__ exit_cur,
-                                                      mss_cand *__restrict__ stack_all, int32_t *__restrict__ segs_all,
+                                                      mss_cand *stack_all, int32_t *__restrict__ segs_all,
                                                       uint64_t *__restrict__ segcnt, int min_sc, double xdrop,
-                                                      uint64_t *__restrict__ grand, int pass)
+                                                      uint64_t *__restrict__ grand, int pass,
+                                                      const double *__restrict__ blk_sum, const double *__restrict__ blk_abs,
+                                                      const int32_t *__restrict__ blk_q, const uint8_t *__restrict__ flags,
+                                                      int have_stats)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nunits) return;
-    const double entry = k == 0 ? 0.0 : exit_prev[k - 1];   // pass 0 reads the zero-initialised buffer
+    __shared__ double sL[MSS_LCAP], sR[MSS_LCAP];
+    __shared__ int32_t sSt[MSS_LCAP], sEn[MSS_LCAP], sPre[MSS_LCAP];
+    const int lane = threadIdx.x;
+    const int64_t k = blockIdx.x;
     const int64_t begin = ustart[k], end = ustart[k + 1];
-    mss_cand *st = stack_all + urun[k];
+    volatile mss_cand *ovf = stack_all + urun[k];               // slots MSS_LCAP.. of this stretch's stack
     int32_t *segs = segs_all + 2 * urun[k];
     int64_t nst = 0, nseg = 0;
-    double L = entry, peak = -1e30;
-    const double NEG = -1e30;
+    double cur = k == 0 ? 0.0 : exit_prev[k - 1];               // L outside a run, R inside one
+    double peak = MSS_NEG;
+    bool run_open = false;
+    int64_t run_st = 0;
+    double run_L = 0.0;
 
+    auto getL = [&](int64_t j) -> double { return j < MSS_LCAP ? sL[j] : ovf[j - MSS_LCAP].L; };
+    auto getR = [&](int64_t j) -> double { return j < MSS_LCAP ? sR[j] : ovf[j - MSS_LCAP].R; };
+    auto getSt = [&](int64_t j) -> int32_t { return j < MSS_LCAP ? sSt[j] : ovf[j - MSS_LCAP].st; };
+    auto getEn = [&](int64_t j) -> int32_t { return j < MSS_LCAP ? sEn[j] : ovf[j - MSS_LCAP].en; };
+    auto getPre = [&](int64_t j) -> int32_t { return j < MSS_LCAP ? sPre[j] : ovf[j - MSS_LCAP].pre; };
+
+    // mss.c:35-47, lane-parallel over the stack
     auto flush = [&]() {
-        for (int64_t j = 0; j < nst; ++j) {
-            const double sc = st[j].R - st[j].L;
-            if (sc >= min_sc) { segs[2 * nseg] = st[j].st; segs[2 * nseg + 1] = st[j].en; ++nseg; }
+        for (int64_t base = 0; base < nst; base += 64) {
+            const int64_t j = base + lane;
+            bool keep = false;
+            int32_t a = 0, b = 0;
+            if (j < nst) {
+                const double sc = getR(j) - getL(j);
+                keep = sc >= min_sc;
+                a = getSt(j);
+                b = getEn(j);
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int64_t slot = nseg + __popcll(m & ((1ull << lane) - 1ull));
+                segs[2 * slot] = a;
+                segs[2 * slot + 1] = b;
+            }
+            nseg += __popcll(m);
         }
         nst = 0;
     };
 
-    int64_t i = begin;
-    while (i < end) {
-        const double s = S[i];
-        if (s > 0) {
-            double R = L + s;
-            int64_t e = i + 1;
-            while (e < end) {
-                const double v = S[e];
-                if (!(v > 0.)) break;
-                R += v;
-                ++e;
+    // a positive run [run_st, en) with prefix values run_L (before) and R (after) is complete: mss.c:65-86
+    auto close_run = [&](double R, int64_t en) {
+        if (R > peak) peak = R;
+        int32_t tst = (int32_t)run_st;
+        double tL = run_L;
+        int64_t j;
+        for (;;) {
+            j = nst - 1;
+            while (j >= 0) {
+                if (getL(j) < tL) break;
+                const int32_t pre = getPre(j);
+                j = pre >= 0 ? pre : j - 1;
             }
-            if (R > peak) peak = R;
-            int32_t tst = (int32_t)i;
-            double tL = L;
-            int64_t j;
-            for (;;) {
-                j = nst - 1;
-                while (j >= 0) {
-                    if (st[j].L < tL) break;
-                    const int32_t pre = st[j].pre;
-                    j = pre >= 0 ? pre : j - 1;
-                }
-                if (j >= 0 && st[j].R < R) {
-                    tst = st[j].st;
-                    tL = st[j].L;
-                    nst = j;
+            if (j >= 0 && getR(j) < R) {
+                tst = getSt(j);
+                tL = getL(j);
+                nst = j;
+                continue;
+            }
+            break;
+        }
+        if (j < 0) { flush(); peak = R; }
+        if (nst < MSS_LCAP) {
+            if (lane == 0) { sL[nst] = tL; sR[nst] = R; sSt[nst] = tst; sEn[nst] = (int32_t)en; sPre[nst] = (int32_t)j; }
+        } else {
+            // every lane stores the same record, so each lane later reads what it wrote itself
+            volatile mss_cand *c = ovf + (nst - MSS_LCAP);
+            c->st = tst; c->en = (int32_t)en; c->L = tL; c->R = R; c->pre = (int32_t)j;
+        }
+        __threadfence_block();
+        ++nst;
+        run_open = false;
+    };
+
+    int64_t pos = begin;
+    while (pos < end) {
+        const int nvalid = (int)min((int64_t)64, end - pos);
+        // ---- (3b) skip whole all-non-positive blocks in the history-free state --------------
+        if (have_stats && !run_open && peak == MSS_NEG && (pos & 63) == 0) {
+            const int64_t b0 = pos >> 6, bend = (end + 63) >> 6;
+            const int64_t bj = b0 + lane;
+            const bool stop = bj >= bend || (flags[bj] & 1) || (bj * 64 + 64 > end);
+            const unsigned long long mstop = __ballot(stop);
+            const int m = mstop ? __builtin_ctzll(mstop) : 64;
+            if (m > 0) {
+                const bool in = lane < m;
+                const double gs = wave_sum(in ? blk_sum[bj] : 0.0);
+                const double ga = wave_sum(in ? blk_abs[bj] : 0.0);
+                const int gq = wave_max(in ? blk_q[bj] : MSS_QNONE);
+                if (mss_certified(cur, ga, gq)) {
+                    cur += gs;
+                    pos += (int64_t)m * 64;
                     continue;
                 }
-                break;
             }
-            if (j < 0) { flush(); peak = R; }
-            mss_cand c;
-            c.st = tst; c.en = (int32_t)e; c.L = tL; c.R = R; c.pre = (int32_t)j; c.pad = 0;
-            st[nst++] = c;
-            L = R;
-            i = e;
-        } else {
-            if (xdrop > 0.0 && L + s + xdrop < peak) { flush(); L = 0.0; peak = NEG; }
-            L += s;
-            ++i;
         }
+        const double s = lane < nvalid ? S[pos + lane] : 0.0;
+        const bool ispos = lane < nvalid && s > 0;
+        const unsigned long long vmask = nvalid == 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+        const unsigned long long mpos = __ballot(ispos);
+        const double sabs = wave_sum(fabs(s));
+        const int q = wave_max(quantum_exp(s));
+        if (mss_certified(cur, sabs, q)) {
+            // ---- (3a) exact prefix sums; V_i = base + pre_i is the reference's running value after element i
+            double pre = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double y = __shfl_up(pre, o);
+                if (lane >= o) pre += y;
+            }
+            double base = cur;
+            int p = 0;
+            while (p < nvalid) {
+                const unsigned long long rest = vmask & ~((1ull << p) - 1ull);     // lanes >= p
+                if ((mpos >> p) & 1ull) {
+                    const unsigned long long z = ~mpos & rest;                     // first non-positive at or after p
+                    const int e = z ? __builtin_ctzll(z) : nvalid;
+                    if (!run_open) { run_open = true; run_st = pos + p; run_L = p == 0 ? base : base + __shfl(pre, p - 1); }
+                    cur = base + __shfl(pre, e - 1);
+                    p = e;
+                    if (e < nvalid) close_run(cur, pos + e);
+                } else {
+                    if (run_open) close_run(cur, pos + p);                       // run ended exactly at the chunk edge
+                    const unsigned long long z = mpos & rest;
+                    const int e = z ? __builtin_ctzll(z) : nvalid;
+                    if (xdrop > 0.0 && peak != MSS_NEG) {
+                        const bool trig = lane >= p && lane < e && ((base + pre) + xdrop < peak);   // mss.c:89
+                        const unsigned long long mt = __ballot(trig);
+                        if (mt) {
+                            const int t = __builtin_ctzll(mt);
+                            flush();
+                            peak = MSS_NEG;
+                            base = t == 0 ? 0.0 : -__shfl(pre, t - 1);          // L = 0 before S[t] is added
+                        }
+                    }
+                    cur = base + __shfl(pre, e - 1);
+                    p = e;
+                }
+            }
+        } else {
+            // ---- certificate failed: the reference loop, element by element ------------------
+            for (int i = 0; i < nvalid; ++i) {
+                const double v = __shfl(s, i);
+                if (v > 0) {
+                    if (!run_open) { run_open = true; run_st = pos + i; run_L = cur; }
+                    cur = cur + v;
+                } else {
+                    if (run_open) close_run(cur, pos + i);
+                    if (xdrop > 0.0 && cur + v + xdrop < peak) { flush(); cur = 0.0; peak = MSS_NEG; }
+                    cur += v;
+                }
+            }
+        }
+        pos += nvalid;
     }
+    if (run_open) close_run(cur, end);
     if (k == nunits - 1) {
         flush();
-    } else if (nst != 0 || peak != NEG) {
-        atomicOr((unsigned long long *)&grand[2], 1ull);    // the forced-reset argument failed: caller falls back
+    } else if (nst != 0 || peak != MSS_NEG) {
+        if (lane == 0) atomicOr((unsigned long long *)&grand[2], 1ull);   // forced-reset argument failed: caller falls back
     }
-    segcnt[k] = (uint64_t)nseg;
-    if (pass == 0 || __double_as_longlong(exit_prev[k]) != __double_as_longlong(L))
-        atomicOr((unsigned long long *)&grand[1], 1ull);
-    exit_cur[k] = L;
+    if (lane == 0) {
+        segcnt[k] = (uint64_t)nseg;
+        if (pass == 0 || __double_as_longlong(exit_prev[k]) != __double_as_longlong(cur))
+            atomicOr((unsigned long long *)&grand[1], 1ull);
+        exit_cur[k] = cur;
+    }
 }
 
 __global__ void __launch_bounds__(256) mss_compact_kernel(const int32_t *__restrict__ segs, const int64_t *__restrict__ urun,
@@ -508,46 +682,50 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
     const double s0 = log(0.99 / (1.0 - 0.99));
     const double xdrop = xdrop_len > 0 ? s0 * xdrop_len * 10.0 : -1;
     const int min_sc = (int)(s0 * min_mss_len);
-    uint8_t *flags = (uint8_t *)l.segs_out;   // scratch until the compaction at the end
+    const double thr = xdrop > 0.0 ? xdrop + 1.0 : -1.0;
+
+    DGRP_HIP(hipMemsetAsync(l.blk, 0, (l.nblk + 1) * 8, stream));
+    hipLaunchKernelGGL(mss_blockstat_kernel, dim3((unsigned)((l.nblk + 3) / 4)), dim3(256), 0, stream, d_scores, n, l.blk,
+                       l.blk_sum, l.blk_abs, l.blk_q, l.flags);
+    DGRP_LAUNCH_CHECK();
 
     bool single = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         int64_t nunits = 1;
         DGRP_HIP(hipMemsetAsync(l.grand, 0, 64, stream));
         if (!single && xdrop > 0.0) {
-            DGRP_HIP(hipMemsetAsync(l.blk, 0, (l.nblk + 1) * 8, stream));
-            hipLaunchKernelGGL(mss_blockstat_kernel, dim3((unsigned)((l.nblk + 3) / 4)), dim3(256), 0, stream, d_scores, n,
-                               xdrop + 1.0, l.blk, flags);
-            DGRP_LAUNCH_CHECK();
-            hipLaunchKernelGGL(mss_boundary_kernel, dim3((unsigned)((l.nblk + 255) / 256)), dim3(256), 0, stream, flags,
-                               l.nblk, l.blk);
-            DGRP_LAUNCH_CHECK();
-            int rc = device_exclusive_scan(l.blk, l.blk, l.nblk, l.tiles, l.grand, stream);
-            if (rc) return rc;
-            hipLaunchKernelGGL(mss_units_kernel, dim3((unsigned)((l.nblk + 255) / 256)), dim3(256), 0, stream, l.blk, flags,
-                               l.nblk, n, l.ustart, l.urun, l.grand);
+            if (attempt == 0) {
+                hipLaunchKernelGGL(mss_boundary_kernel, dim3((unsigned)((l.nblk + 255) / 256)), dim3(256), 0, stream,
+                                   l.flags, l.blk_sum, l.nblk, n, thr, l.blk);
+                DGRP_LAUNCH_CHECK();
+                int rc = device_exclusive_scan(l.blk, l.blk, l.nblk, l.tiles, l.grand, stream);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL(mss_units_kernel, dim3((unsigned)((l.nblk + 255) / 256)), dim3(256), 0, stream, l.blk, l.flags,
+                               l.blk_sum, l.nblk, n, thr, l.ustart, l.urun, l.grand);
             DGRP_LAUNCH_CHECK();
             uint64_t g = 0;
             DGRP_HIP(hipMemcpyAsync(&g, l.grand, 8, hipMemcpyDeviceToHost, stream));
             DGRP_HIP(hipStreamSynchronize(stream));
             nunits = (int64_t)(g >> 32) + 1;
         } else {
-            // one stretch: the plain sequential scan
+            // one stretch: the plain sequential scan (still chunked and certified)
             int64_t h[2] = { 0, n };
             DGRP_HIP(hipMemcpyAsync(l.ustart, h, 16, hipMemcpyHostToDevice, stream));
             int64_t r[2] = { 0, 0 };
             DGRP_HIP(hipMemcpyAsync(l.urun, r, 16, hipMemcpyHostToDevice, stream));
             DGRP_HIP(hipStreamSynchronize(stream));
         }
+        DGRP_REQUIRE(nunits < (1ll << 31), "dgrp_mss_labels: too many stretches");
         DGRP_HIP(hipMemsetAsync(l.exitL[0], 0, nunits * 8, stream));
         DGRP_HIP(hipMemsetAsync(l.exitL[1], 0, nunits * 8, stream));
         bool failed = false;
         for (int pass = 0;; ++pass) {
             // pass p reads the exits of pass p-1 from exitL[(p+1)&1] and writes exitL[p&1]
             DGRP_HIP(hipMemsetAsync(l.grand + 1, 0, 8, stream));
-            hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)((nunits + 63) / 64)), dim3(64), 0, stream, d_scores,
-                               l.ustart, l.urun, nunits, l.exitL[(pass + 1) & 1], l.exitL[pass & 1], l.stack, l.segs,
-                               l.segcnt, min_sc, xdrop, l.grand, pass);
+            hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)nunits), dim3(64), 0, stream, d_scores, l.ustart, l.urun,
+                               nunits, l.exitL[(pass + 1) & 1], l.exitL[pass & 1], l.stack, l.segs, l.segcnt, min_sc, xdrop,
+                               l.grand, pass, l.blk_sum, l.blk_abs, l.blk_q, l.flags, 1);
             DGRP_LAUNCH_CHECK();
             uint64_t g[3] = { 0, 0, 0 };
             DGRP_HIP(hipMemcpyAsync(g, l.grand, 24, hipMemcpyDeviceToHost, stream));

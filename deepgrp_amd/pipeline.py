@@ -139,6 +139,7 @@ class ContigPipeline:
         self.xdrop_len = int(xdrop_len)
         self.use_mss = bool(use_mss)
         self.chunk_windows = int(chunk_windows)
+        self.event_log = None        # bench.py: list collecting (start, end, windows) per GRU launch
         if self.step < 1 or self.batch < 1:
             raise ValueError("step_size and batch_size must be >= 1")
 
@@ -160,8 +161,14 @@ class ContigPipeline:
             wb = L.dgrp_forward_workspace_bytes(m.handle, nw)
             if work is None or work.numel() < wb:
                 work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
+            if self.event_log is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             check(L.dgrp_forward_merge(m.handle, _ptr(d_idx), n, self.step, self.batch, w0, nw, _ptr(out),
                                        _ptr(work), work.numel(), stream_ptr()), "dgrp_forward_merge")
+            if self.event_log is not None:
+                ev1.record()
+                self.event_log.append((ev0, ev1, nw))
             w0 += nw
         return out
 
