@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""deepgrp_amd command line -- drop-in for `deepgrp [flags] predict <model.hdf5> <FASTA>...`
+(deepgrp/__main__.py:86-297 of the reference): same flags and defaults, same 5-column TSV.
+
+Differences, all additive:
+  * the README's short form `deepgrp <modelfile> <fastafile>` is accepted too;
+  * `--xla` and `--threads` are accepted and ignored (there is no TensorFlow here);
+  * under torchrun (WORLD_SIZE > 1) the records of all input files are sharded by contig over
+    the GPUs and rank 0 writes the rows in input order;
+  * `train` exits with an error: training is TensorFlow's job in the reference and out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+from typing import Iterator, List, TextIO, Tuple
+
+import numpy as np
+
+logging.basicConfig()
+_LOG = logging.getLogger(__name__)
+
+
+def _read_multi_fasta(filestream: TextIO) -> Iterator[Tuple[str, str]]:
+    """Reads a multi FASTA file (deepgrp/__main__.py:20-43): header = text after '>', sequence
+    lines upper-cased and joined; a record without header is dropped; a blank line raises
+    IndexError exactly like `line[0]` does in the reference."""
+    _LOG.debug("Reading FASTA file.")
+    header = ""
+    sequence: List[str] = []
+    for line in filestream:
+        line = line.strip()
+        if line[0] == ">":
+            if header:
+                yield header, "".join(sequence)
+            header = line[1:]
+            sequence = []
+        else:
+            sequence.append(line.upper())
+    if header:
+        yield header, "".join(sequence)
+
+
+def _predict(dnasequence: str, model, options, step_size: int, use_mss: bool) -> Tuple[np.ndarray, int]:
+    """Runs a prediction for one sequence (deepgrp/__main__.py:46-83): returns the label per base
+    (int64, after MSS or the softmax path) and the number of leading N's."""
+    from .pipeline import ContigPipeline, upload_sequence
+    _LOG.debug("One hot encoding sequence.")
+    start_pos, d_idx = upload_sequence(dnasequence.encode("utf-8"))
+    _LOG.debug("Start prediction.")
+    pipe = ContigPipeline(model, step_size, options.batch_size, options.min_mss_len, options.xdrop_len, use_mss)
+    merged = pipe.merged(d_idx)
+    _LOG.debug("Finish prediction.")
+    if use_mss:
+        _LOG.debug("Applying MSS.")
+    labels = pipe.labels(merged)
+    return labels.cpu().numpy().astype(np.int64), start_pos
+
+
+class CommandLineParser:
+    """Commandline parser (deepgrp/__main__.py:86-250)."""
+
+    def __init__(self, **kwargs):
+        kwargs.setdefault("prog", "deepgrp")
+        kwargs.setdefault("formatter_class", argparse.ArgumentDefaultsHelpFormatter)
+        kwargs.setdefault("description", "DeepGRP - Prediction of repetitive elements (MI355X / HIP)")
+        self.parser = argparse.ArgumentParser(**kwargs)
+        self.args = None
+        self.threads = 1
+        self.xla = False
+        self.verbose = 0
+        subparsers = self.parser.add_subparsers(help="sub-command help", dest="command")
+        self.parser.add_argument("--batch_size", "-b", type=int, default=256,
+                                 help="Batch size of the reference's TensorFlow loop; only its placement arithmetic matters here")
+        self.parser.add_argument("--step_size", "-s", type=int, default=50, help="Window step size")
+        self.parser.add_argument("--xdrop_length", "-x", type=int, default=50,
+                                 help="XDrop parameter for MSS algorithm, ignored if --no_use_mss, disabled with values<0")
+        self.parser.add_argument("--min_mss_length", "-l", type=int, default=50,
+                                 help="Minimal length of maximum scoring segments, ignored if --no_use_mss")
+        self.parser.add_argument("--threads", "-t", type=int, default=1, help="Accepted for compatibility (ignored)")
+        self.parser.add_argument("--xla", action="store_true", help="Accepted for compatibility (ignored)")
+        self.parser.add_argument("-v", "--verbose", action="count", default=0, help="Increase verbosity")
+        train = subparsers.add_parser(name="train", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                                      description="Train a deepgrp model (not available in deepgrp_amd)")
+        train.add_argument("parameter", type=str)
+        train.add_argument("trainfile", type=str)
+        train.add_argument("validfile", type=str)
+        train.add_argument("bedfile", type=str)
+        train.add_argument("--logdir", type=str, default=".")
+        train.add_argument("--modelfile", type=str, default="model.hdf5")
+        predict = subparsers.add_parser(name="predict", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                                        description="predict using a deepgrp model")
+        predict.add_argument("model", type=str, help="Keras model in HDF5 format")
+        predict.add_argument("FASTA", nargs="+", type=str, help="Fasta input files ('-' = stdin)")
+        predict.add_argument("--output", type=str, default="-", help="Output filename")
+        predict.add_argument("--no_use_mss", "-m", action="store_true", help="Disable maximum scoring segment algorithm")
+
+    def parse_args(self, argv=None) -> "CommandLineParser":
+        argv = list(sys.argv[1:] if argv is None else argv)
+        # README form `deepgrp <modelfile> <fastafile>`: insert the sub-command before the first positional
+        if not any(a in ("predict", "train") for a in argv):
+            takes_value = {"--batch_size", "-b", "--step_size", "-s", "--xdrop_length", "-x", "--min_mss_length", "-l",
+                           "--threads", "-t"}
+            i = 0
+            while i < len(argv):
+                if argv[i] in takes_value:
+                    i += 2
+                elif argv[i].startswith("-") and argv[i] != "-":
+                    i += 1
+                else:
+                    break
+            if i < len(argv):
+                argv.insert(i, "predict")
+        args = self.parser.parse_args(argv)
+        if args.command is None:
+            self.parser.error("a sub-command (predict) is required")
+        self.threads, self.verbose, self.xla, self.args = args.threads, args.verbose, args.xla, args
+        return self
+
+    def setup_tensorflow(self) -> "CommandLineParser":
+        """Kept for call-chain compatibility (deepgrp/__main__.py:221-233); nothing to set up."""
+        return self
+
+    def set_logging(self) -> "CommandLineParser":
+        levels = [logging.WARNING, logging.INFO, logging.DEBUG]
+        _LOG.setLevel(levels[min(len(levels) - 1, self.verbose)])
+        return self
+
+    def run(self):
+        from . import model as dgmodel
+        options = dgmodel.Options(min_mss_len=self.args.min_mss_length, batch_size=self.args.batch_size,
+                                  xdrop_len=self.args.xdrop_length)
+        getattr(self, self.args.command)(self.args, options)
+
+    @staticmethod
+    def predict(args: argparse.Namespace, options) -> None:
+        """Predict with deepgrp (deepgrp/__main__.py:252-297)."""
+        import torch
+        import torch.distributed as dist
+        from . import model as dgmodel
+        from .distributed import gather_records, shard_contigs
+        from .pipeline import SEGMENT_DTYPE, ContigPipeline, upload_sequence
+
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        if world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl")
+
+        _LOG.debug("Loading model %s!", args.model)
+        model = dgmodel.load_model(args.model, custom_objects={"ReverseComplement": None})
+        options.vecsize = model.input_shape[1]
+        _LOG.info("Model loading finished successfully!")
+        pipe = ContigPipeline(model, args.step_size, options.batch_size, options.min_mss_len, options.xdrop_len,
+                              use_mss=not args.no_use_mss)
+        outstream = None
+        if rank == 0:
+            outstream = sys.stdout if args.output == "-" else open(args.output, "w")
+
+        def rows_text(filename: str, header: str, rows) -> str:
+            return "".join("{}\t{}\t{}\t{}\t{}\n".format(filename, header, int(r["start"]), int(r["end"]), int(r["label"]))
+                           for r in rows)
+
+        if world == 1:
+            for filename in args.FASTA:
+                _LOG.info("Processing %s", filename)
+                filestream = sys.stdin if filename == "-" else open(filename, "r")
+                try:
+                    for header, dnasequence in _read_multi_fasta(filestream):
+                        rows = pipe.run(dnasequence)
+                        outstream.write(rows_text(filename, header, rows))
+                finally:
+                    if filename != "-":
+                        filestream.close()
+        else:
+            # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
+            records = []
+            for filename in args.FASTA:
+                filestream = sys.stdin if filename == "-" else open(filename, "r")
+                try:
+                    for header, dnasequence in _read_multi_fasta(filestream):
+                        records.append((filename, header, dnasequence))
+                finally:
+                    if filename != "-":
+                        filestream.close()
+            mine = shard_contigs([len(r[2]) for r in records], world)[rank]
+            parts = [pipe.run(records[i][2], contig=i) for i in mine]
+            local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
+            allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
+            if rank == 0:
+                for i, (filename, header, _seq) in enumerate(records):
+                    outstream.write(rows_text(filename, header, allrows[allrows["contig"] == i]))
+            dist.barrier()
+        if rank == 0 and args.output != "-":
+            outstream.close()
+
+    @staticmethod
+    def train(args: argparse.Namespace, options) -> None:
+        sys.exit("deepgrp_amd implements the prediction path only; train with the reference (TensorFlow) and "
+                 "pass the saved .hdf5 to `predict`")
+
+
+def main(argv=None):
+    CommandLineParser().parse_args(argv).set_logging().setup_tensorflow().run()
+
+
+if __name__ == "__main__":
+    main()

@@ -278,6 +278,10 @@ struct mss_layout {            // carve of the caller's workspace
     double *blk_abs;           // [nblk] sum of |score|
     int32_t *blk_q;            // [nblk] smallest Q with every score a multiple of 2^-Q
     uint8_t *flags;            // [nblk] bit0: contains a positive score
+    int64_t nsup;              // 64-block groups (4096 scores)
+    double *sup_sum, *sup_abs; // [nsup]
+    int32_t *sup_q;            // [nsup]
+    uint8_t *sup_flags;        // [nsup] bit0: contains a positive score
     uint64_t *tiles;           // scan scratch
     uint64_t *grand;           // [8]: [0] scan total, [1] changed flag, [2] error flag, [3] total kept segments
     int64_t *ustart;           // [nunits+1] stretch starts
@@ -302,6 +306,11 @@ static mss_layout mss_carve(void *work, int64_t n)
     l.blk_abs = (double *)take(l.nblk * 8);
     l.blk_q = (int32_t *)take(l.nblk * 4);
     l.flags = (uint8_t *)take(l.nblk + 64);
+    l.nsup = (l.nblk + 63) / 64;
+    l.sup_sum = (double *)take(l.nsup * 8);
+    l.sup_abs = (double *)take(l.nsup * 8);
+    l.sup_q = (int32_t *)take(l.nsup * 4);
+    l.sup_flags = (uint8_t *)take(l.nsup + 64);
     l.tiles = (uint64_t *)take(((maxunits + 1 + SCAN_TILE - 1) / SCAN_TILE + 1) * 8);
     l.grand = (uint64_t *)take(64);
     l.ustart = (int64_t *)take((maxunits + 1) * 8);
@@ -385,6 +394,28 @@ __global__ void __launch_bounds__(256) mss_blockstat_kernel(const double *__rest
     }
 }
 
+// Second level of the skip table: one wave per 64 blocks (4096 scores).
+__global__ void __launch_bounds__(256) mss_superstat_kernel(const double *__restrict__ blk_sum, const double *__restrict__ blk_abs,
+                                                            const int32_t *__restrict__ blk_q, const uint8_t *__restrict__ flags,
+                                                            int64_t nblk, double *__restrict__ sup_sum, double *__restrict__ sup_abs,
+                                                            int32_t *__restrict__ sup_q, uint8_t *__restrict__ sup_flags)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g * 64 >= nblk) return;
+    const int64_t b = g * 64 + lane;
+    const bool in = b < nblk;
+    const unsigned long long mp = __ballot(in && (flags[b] & 1));
+    const double sum = wave_sum(in ? blk_sum[b] : 0.0), sabs = wave_sum(in ? blk_abs[b] : 0.0);
+    const int q = wave_max(in ? blk_q[b] : MSS_QNONE);
+    if (lane == 0) {
+        sup_flags[g] = (uint8_t)(mp != 0ull ? 1 : 0);
+        sup_sum[g] = sum;
+        sup_abs[g] = sabs;
+        sup_q[g] = q;
+    }
+}
+
 // A cut goes after block b when b ends a chain of all-non-positive blocks, the next block has a
 // positive score, and the last (up to 16) blocks of the chain sum below -thr (forced reset).
 __device__ __forceinline__ bool mss_is_boundary(const uint8_t *flags, const double *blk_sum, int64_t b, int64_t nblk,
@@ -440,6 +471,8 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                                                       uint64_t *__restrict__ grand, int pass,
                                                       const double *__restrict__ blk_sum, const double *__restrict__ blk_abs,
                                                       const int32_t *__restrict__ blk_q, const uint8_t *__restrict__ flags,
+                                                      const double *__restrict__ sup_sum, const double *__restrict__ sup_abs,
+                                                      const int32_t *__restrict__ sup_q, const uint8_t *__restrict__ sup_flags,
                                                       int have_stats)
 {
     __shared__ double sL[MSS_LCAP], sR[MSS_LCAP];
@@ -524,9 +557,28 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
         const int nvalid = (int)min((int64_t)64, end - pos);
         // ---- (3b) skip whole all-non-positive blocks in the history-free state --------------
         if (have_stats && !run_open && peak == MSS_NEG && (pos & 63) == 0) {
+            if ((pos & 4095) == 0) {
+                // 64 groups of 4096 scores at a time
+                const int64_t gj = (pos >> 12) + lane;
+                const bool stop2 = gj * 4096 + 4096 > end || (sup_flags[gj] & 1);
+                const unsigned long long ms2 = __ballot(stop2);
+                const int m2 = ms2 ? __builtin_ctzll(ms2) : 64;
+                if (m2 > 0) {
+                    const bool in = lane < m2;
+                    const double gs = wave_sum(in ? sup_sum[gj] : 0.0);
+                    const double ga = wave_sum(in ? sup_abs[gj] : 0.0);
+                    const int gq = wave_max(in ? sup_q[gj] : MSS_QNONE);
+                    if (mss_certified(cur, ga, gq)) {
+                        cur += gs;
+                        pos += (int64_t)m2 * 4096;
+                        continue;
+                    }
+                }
+            }
             const int64_t b0 = pos >> 6, bend = (end + 63) >> 6;
             const int64_t bj = b0 + lane;
-            const bool stop = bj >= bend || (flags[bj] & 1) || (bj * 64 + 64 > end);
+            // stop at the next 4096-aligned position so that the coarser level takes over there
+            const bool stop = bj >= bend || (flags[bj] & 1) || (bj * 64 + 64 > end) || (lane > 0 && (bj & 63) == 0);
             const unsigned long long mstop = __ballot(stop);
             const int m = mstop ? __builtin_ctzll(mstop) : 64;
             if (m > 0) {
@@ -688,6 +740,9 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
     hipLaunchKernelGGL(mss_blockstat_kernel, dim3((unsigned)((l.nblk + 3) / 4)), dim3(256), 0, stream, d_scores, n, l.blk,
                        l.blk_sum, l.blk_abs, l.blk_q, l.flags);
     DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mss_superstat_kernel, dim3((unsigned)((l.nsup + 3) / 4)), dim3(256), 0, stream, l.blk_sum, l.blk_abs,
+                       l.blk_q, l.flags, l.nblk, l.sup_sum, l.sup_abs, l.sup_q, l.sup_flags);
+    DGRP_LAUNCH_CHECK();
 
     bool single = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -725,7 +780,8 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
             DGRP_HIP(hipMemsetAsync(l.grand + 1, 0, 8, stream));
             hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)nunits), dim3(64), 0, stream, d_scores, l.ustart, l.urun,
                                nunits, l.exitL[(pass + 1) & 1], l.exitL[pass & 1], l.stack, l.segs, l.segcnt, min_sc, xdrop,
-                               l.grand, pass, l.blk_sum, l.blk_abs, l.blk_q, l.flags, 1);
+                               l.grand, pass, l.blk_sum, l.blk_abs, l.blk_q, l.flags, l.sup_sum, l.sup_abs, l.sup_q,
+                               l.sup_flags, 1);
             DGRP_LAUNCH_CHECK();
             uint64_t g[3] = { 0, 0, 0 };
             DGRP_HIP(hipMemcpyAsync(g, l.grand, 24, hipMemcpyDeviceToHost, stream));

@@ -8,33 +8,68 @@ from typing import Dict, Optional
 import numpy as np
 
 
-def synthetic_chromosome(n_bases: int, contig: int = 0, n_frac: float = 0.01, flank: int = 10_000,
-                         structured: bool = True) -> bytes:
-    """Upper-case sequence bytes: leading/trailing N blocks of `flank` (exercises startpos),
-    N injected at `n_frac`, bases i.i.d. uniform; with `structured`, stretches of
-    low-complexity repeats (random short motifs tandemly repeated) are planted so that the
-    model's output is not stationary noise.  numpy.random.default_rng(seed=20240+contig)."""
+def _planted(n_bases: int, contig: int, n_frac: float, flank: int, structured: bool):
+    """(class index per base incl. flanks as 4, truth label per base)."""
     rng = np.random.default_rng(20240 + contig)
     body = n_bases - 2 * flank
     if body <= 0:
         flank, body = 0, n_bases
     seq = rng.integers(0, 4, size=body, dtype=np.uint8)
+    truth = np.zeros(body, np.uint8)
     if structured and body > 4000:
         pos = 0
         while pos < body:
-            pos += int(rng.integers(2_000, 40_000))
-            ln = int(rng.integers(300, 6_000))
+            pos += int(rng.integers(500, 12_000))
+            ln = int(rng.integers(150, 4_000))
             if pos + ln >= body:
                 break
-            motif = rng.integers(0, 4, size=int(rng.integers(1, 7)), dtype=np.uint8)
-            seq[pos:pos + ln] = np.resize(motif, ln)
+            period = int(rng.integers(1, 7))
+            motif = rng.integers(0, 4, size=period, dtype=np.uint8)
+            if period > 1 and (motif == motif[0]).all():
+                motif[-1] = (motif[0] + 1) % 4
+            unit = np.resize(motif, ln)
+            mut = rng.random(ln) < 0.03                          # a few substitutions, like real tandem repeats
+            unit = np.where(mut, rng.integers(0, 4, size=ln, dtype=np.uint8), unit)
+            seq[pos:pos + ln] = unit
+            truth[pos:pos + ln] = PERIOD_CLASS[period]
             pos += ln
-    lut = np.frombuffer(b"ACGTN", dtype=np.uint8)
     if n_frac > 0:
         seq = seq.copy()
         seq[rng.random(body) < n_frac] = 4
-    out = np.concatenate([np.full(flank, ord("N"), np.uint8), lut[seq], np.full(flank, ord("N"), np.uint8)])
-    return out.tobytes()
+    idx = np.concatenate([np.full(flank, 4, np.uint8), seq, np.full(flank, 4, np.uint8)])
+    lab = np.concatenate([np.zeros(flank, np.uint8), truth, np.zeros(flank, np.uint8)])
+    return idx, lab
+
+
+# repeat class of a planted tandem repeat by its period (4 repeat classes like repeats_to_search)
+PERIOD_CLASS = {1: 1, 2: 1, 3: 2, 4: 3, 5: 3, 6: 4}
+
+
+def synthetic_chromosome(n_bases: int, contig: int = 0, n_frac: float = 0.01, flank: int = 10_000,
+                         structured: bool = True) -> bytes:
+    """Upper-case sequence bytes: leading/trailing N blocks of `flank` (exercises startpos),
+    N injected at `n_frac`, bases i.i.d. uniform; with `structured`, tandem repeats of period
+    1-6 (150-4000 bp, 3 % substitutions) are planted every 0.5-12 kb -- the "repeats" the
+    trained synthetic model (data/synthetic_gru128.npz) calls.
+    numpy.random.default_rng(seed=20240+contig)."""
+    idx, _ = _planted(n_bases, contig, n_frac, flank, structured)
+    return np.frombuffer(b"ACGTN", dtype=np.uint8)[idx].tobytes()
+
+
+def synthetic_truth(n_bases: int, contig: int = 0, n_frac: float = 0.01, flank: int = 10_000):
+    """(class index uint8 [n], truth label uint8 [n]) of the same chromosome."""
+    return _planted(n_bases, contig, n_frac, flank, True)
+
+
+def trained_weights(path: Optional[str] = None) -> Dict[str, Optional[np.ndarray]]:
+    """The small model tools/train_synth_model.py fitted (torch, CPU) to call the planted tandem
+    repeats: u=128, T=200, 5 classes, no attention -- genome-like output (confident background,
+    confident repeat runs) for benchmarks; there is no trained DeepGRP model offline."""
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "synthetic_gru128.npz")
+    z = np.load(path, allow_pickle=False)
+    return dict(kernel=z["kernel"], recurrent_kernel=z["recurrent_kernel"], bias=z["bias"], ff_kernel=z["ff_kernel"],
+                ff_bias=z["ff_bias"], scale=None)
 
 
 def synthetic_weights(units: int = 128, classes: int = 5, attention: bool = False, seed: int = 7,

@@ -1,0 +1,249 @@
+"""The reference's Python API (deepgrp.sequence / .mss / .prediction / .model / CLI) through the
+mirror modules of deepgrp_amd, on the GPU.  Reference tests are replayed where they exist."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from deepgrp_amd import mss as dgmss                      # noqa: E402
+from deepgrp_amd import model as dgmodel                  # noqa: E402
+from deepgrp_amd import prediction as dgpredict           # noqa: E402
+from deepgrp_amd import sequence as dgseq                 # noqa: E402
+from deepgrp_amd import synthetic                         # noqa: E402
+
+
+def test_one_hot_encode_dna_sequence():
+    """tests/test_sequence.py:10-27 of the reference."""
+    data = "NNNN" + "".join(np.random.default_rng(0).choice(["A", "C", "G", "T", "N"], size=100)) + "NNNN"
+    startpos, one_hot = dgseq.one_hot_encode_dna_sequence(data)
+    assert one_hot.dtype == np.int8 and one_hot.shape[0] == 5
+    np.testing.assert_equal(one_hot.sum(axis=0), 1)
+    expected = data.translate(str.maketrans({"A": "0", "C": "1", "G": "2", "T": "3", "N": "4"})).strip("4")
+    np.testing.assert_equal(one_hot.argmax(axis=0), np.array(list(expected)).astype(int))
+    assert all(c == "N" for c in data[:startpos]) and data[startpos] != "N"
+    with pytest.raises(ValueError):
+        dgseq.one_hot_encode_dna_sequence("NNN")
+    g = golden("onehot.npz")
+    for i in range(int(g["count"])):
+        st, oh = dgseq.one_hot_encode_dna_sequence(bytes(g[f"seq{i}"]).decode())
+        assert st == int(g[f"start{i}"])
+        np.testing.assert_array_equal(oh, g[f"onehot{i}"])
+
+
+@pytest.mark.parametrize("stride", [1, 2, 3])
+def test_get_max(stride):
+    """tests/test_sequence.py:47-56 of the reference."""
+    testdata = np.zeros((10, 100, 5), dtype=np.float32)
+    testdata[:, 0, :] = 1.0
+    output = np.zeros((10000, 5), dtype=np.float32)
+    got = dgseq.get_max(output, testdata, stride=stride)
+    assert got is output
+    for i in range(0, stride * 10, stride):
+        np.testing.assert_equal(got[i], 1)
+        got[i] -= 1.0
+    np.testing.assert_equal(got, 0)
+
+
+def test_get_max_argument_errors():
+    out = np.zeros((10, 5), np.float32)
+    with pytest.raises(TypeError):
+        dgseq.get_max(out, [[[1.0]]], 1)                      # prediction.predict relies on TypeError
+    with pytest.raises(ValueError):
+        dgseq.get_max(out.astype(np.float64), np.zeros((1, 2, 5), np.float32), 1)
+    with pytest.raises(ValueError):
+        dgseq.get_max(out, np.zeros((2, 5), np.float32), 1)
+    with pytest.raises(ValueError):
+        dgseq.get_max(np.zeros((10, 10), np.float32)[:, ::2], np.zeros((1, 2, 5), np.float32), 1)
+
+
+def test_yield_segments_golden():
+    g = golden("segments.npz")
+    for k in range(int(g["count"])):
+        got = np.array(list(dgseq.yield_segments(g[f"lab{k}"], 5)), np.int64).reshape(-1, 3)
+        np.testing.assert_array_equal(got, g[f"all{k}"])
+    assert list(dgseq.yield_segments(np.zeros(0, np.int64), 3)) == []
+
+
+@pytest.mark.parametrize("min_mss_len", [0, 3, 10])
+@pytest.mark.parametrize("xdrop_len", [-1, 0, 10])
+def test_find_mss_labels(min_mss_len, xdrop_len):
+    """tests/test_mss.py:10-24 of the reference."""
+    scores = np.array([1, 1, -1, 1, 1, -4, 1, 1, -10, 1, 1, -1, 1, 1], dtype=np.float64)
+    labels = np.array([1, 1, 0, 1, 1, 0, 2, 2, 0, 1, 1, 0, 2, 2], dtype=int)
+    got = dgmss.find_mss_labels(scores, labels, 3, min_mss_len, xdrop_len)
+    assert got.shape == (14, 3) and got.dtype == np.float64
+    np.testing.assert_equal(got.sum(axis=1), 1)
+    expected = labels.copy()
+    if min_mss_len == 0:
+        expected[2] = 1
+        expected[11] = 1
+    np.testing.assert_equal(got.argmax(axis=1), expected)
+    with pytest.raises(TypeError):
+        dgmss.find_mss_labels(None, labels, 3, 0, 0)
+    with pytest.raises(ValueError):
+        dgmss.find_mss_labels(scores.astype(np.float32), labels, 3, 0, 0)
+
+
+@pytest.mark.parametrize("step_size", [2, 4])
+@pytest.mark.parametrize("batch_size", [3, 10])
+@pytest.mark.parametrize("vecsize", [20, 30])
+def test_fetch_validation_batch(step_size, batch_size, vecsize):
+    """tests/test_prediction.py:16-36 of the reference (random float matrix)."""
+    for testdata in (np.random.default_rng(1).random((5, 200)),
+                     np.eye(5, dtype=np.int8)[np.random.default_rng(2).integers(0, 5, 200)].T.copy()):
+        got = dgpredict.fetch_validation_batch(data=testdata, step_size=step_size, batch_size=batch_size, vecsize=vecsize)
+        assert list(got.element_shape) == [None, vecsize, 5]
+        i = 0
+        total = np.ceil((testdata.shape[1] - vecsize) / step_size)
+        for tmp in got.as_numpy_iterator():
+            assert tmp.shape == (min(total, batch_size), vecsize, testdata.shape[0]) and tmp.dtype == np.float32
+            for element in tmp:
+                np.testing.assert_allclose(element, testdata.T[i * step_size:i * step_size + vecsize])
+                i += 1
+            total -= tmp.shape[0]
+        assert total == 0
+
+
+@pytest.mark.parametrize("min_mss_len,xdrop_len", [(2, 3), (4, 10), (50, 50)])
+@pytest.mark.parametrize("n_classes", [3, 5])
+def test_apply_mss(orc, min_mss_len, xdrop_len, n_classes):
+    """tests/test_prediction.py:39-64 of the reference checks the score transform through a mock;
+    here the whole function is compared with the oracle (scores, classes, labels)."""
+    testdata = np.random.default_rng(n_classes).random((200, n_classes)).astype(np.float32)
+    opt = dgmodel.Options(min_mss_len=min_mss_len, xdrop_len=xdrop_len)
+    got = dgpredict.apply_mss(testdata, opt)
+    sc, cl = orc.scores(testdata)
+    sc_g, cl_g = dgpredict._scores_and_classes(testdata)
+    np.testing.assert_array_equal(cl_g, testdata.argmax(axis=1))
+    np.testing.assert_array_equal(sc_g.view(np.int64), sc.view(np.int64))
+    expected_scores = np.log(np.minimum(testdata.max(axis=1) + 1e-6, 0.99) / (1 - np.minimum(testdata.max(axis=1) + 1e-6, 0.99)))
+    chk = sc_g.copy()
+    chk[cl_g == 0] /= -10
+    np.testing.assert_allclose(chk, expected_scores, rtol=1e-5)
+    assert got.shape == (200, n_classes) and got.dtype == np.float64
+    np.testing.assert_array_equal(got.argmax(axis=1), orc.find_mss_labels(sc, cl, n_classes, min_mss_len, xdrop_len))
+
+
+def test_softmax():
+    """tests/test_prediction.py:67-71 of the reference + the float32 golden vector (bit exact)."""
+    import scipy.special
+    testdata = np.random.default_rng(0).random((200, 10))
+    np.testing.assert_allclose(dgpredict.softmax(testdata), scipy.special.softmax(testdata, axis=1))
+    g = golden("softmax.npz")
+    np.testing.assert_array_equal(dgpredict.softmax(g["probs"]).view(np.int32), g["softmax"].view(np.int32))
+
+
+class _ConstModel:
+    def __init__(self, out):
+        self.out = out
+
+    def predict_on_batch(self, batch):
+        return self.out[: batch.shape[0]]
+
+
+@pytest.mark.parametrize("step_size", (1, 2))
+def test_predict_generic_loop(step_size):
+    """tests/test_prediction.py:74-93 of the reference with a constant fake model."""
+    tmp = np.zeros((4, 10, 3), np.float32)
+    tmp[:, 0, 1] = 1
+    testdata = (np.random.rand(4, 10, 5) for _ in range(3))
+    got = dgpredict.predict(model=_ConstModel(tmp), data=testdata, results_shape=(50, 3), step_size=step_size)
+    np.testing.assert_array_equal(got.sum(axis=0), [0, 12, 0])
+    for i in range(0, 12):
+        np.testing.assert_equal(got[i * step_size], [0, 1, 0])
+
+
+@pytest.mark.parametrize("N,B", [(1050, 4), (1001, 5), (3000, 256)])
+def test_predict_fused_equals_generic(orc, N, B):
+    """deepgrp.prediction.predict with a loaded model: the fused device path and the reference's
+    batch loop (predict_on_batch + get_max) give the same array, incl. the short-batch offset."""
+    model = dgmodel.load_model(os.path.join(GOLDEN, "model_u8_T20.h5"))
+    rng = np.random.default_rng(N)
+    seq = "".join(rng.choice(list("ACGTN"), size=N, p=[.24, .24, .24, .24, .04]))
+    seq = "A" + seq[1:-1] + "C"
+    _, onehot = dgseq.one_hot_encode_dna_sequence(seq)
+    T = model.input_shape[1]
+    ds = dgpredict.fetch_validation_batch(onehot, 7, B, T)
+    fused = dgpredict.predict(model, ds, (onehot.shape[1], model.output_shape[2]), 7)
+    generic = dgpredict.predict(model, iter(ds), (onehot.shape[1], model.output_shape[2]), 7)
+    np.testing.assert_array_equal(fused, generic)
+    z = np.load(os.path.join(GOLDEN, "model_u8_T20.npz"))
+    w = orc.Weights(z["kernel"], z["recurrent_kernel"], z["bias"], z["ff_kernel"], z["ff_bias"], None, T)
+    idx = onehot.argmax(axis=0).astype(np.uint8)
+    nwin = orc.window_count(N, T, 7)
+    ref = orc.merge_all(orc.nn_forward(idx, w, 7, 0, nwin, np.float64).astype(np.float32), N, 7, B)
+    assert np.abs(fused - ref).max() < 1e-3
+
+
+@pytest.mark.parametrize("name", ["model_u8_T20", "model_u60_T342_att", "model_u16_T30_att_vlen"])
+def test_load_model_and_predict_on_batch(orc, name):
+    model = dgmodel.load_model(os.path.join(GOLDEN, name + ".h5"), custom_objects={"ReverseComplement": None})
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    T, C = int(z["T"]), int(z["C"])
+    assert model.input_shape == (None, T, 5) and model.output_shape == (None, T, C)
+    w = orc.Weights(z["kernel"], z["recurrent_kernel"], z["bias"], z["ff_kernel"], z["ff_bias"],
+                    z["scale"] if bool(z["attention"]) else None, T)
+    idx = np.random.default_rng(5).integers(0, 5, size=T * 9).astype(np.uint8)
+    batch = np.eye(5, dtype=np.float32)[idx].reshape(9, T, 5)
+    got = model.predict_on_batch(batch)
+    assert np.abs(got - orc.nn_forward(idx, w, T, 0, 9, np.float64)).max() < 1e-3
+
+
+def _expected_tsv(orc, fasta_path, model_file, npz, step, B, ml, xd, use_mss):
+    """What the reference CLI would print, computed by the oracle from the GPU's own probabilities."""
+    from deepgrp_amd.pipeline import upload_sequence
+    model = dgmodel.load_model(model_file)
+    T, C = model.input_shape[1], model.output_shape[2]
+    out = []
+    with open(fasta_path) as fh:
+        for header, seq in orc.read_multi_fasta(fh):
+            st, d_idx = upload_sequence(seq.encode())
+            nwin = orc.window_count(d_idx.numel(), T, step)
+            probs = model.forward_windows(d_idx, step, 0, nwin).cpu().numpy() if nwin else np.zeros((0, T, C), np.float32)
+            rows = orc.predict_contig(seq, lambda _i: (lambda a, b: probs[a:a + b]), T, C, step, B, ml, xd, use_mss)
+            out += [f"{fasta_path}\t{header}\t{a}\t{b}\t{c}\n" for a, b, c in rows]
+    return "".join(out)
+
+
+@pytest.mark.parametrize("argv_style,use_mss", [("reference", True), ("readme", True), ("reference", False)])
+def test_cli_end_to_end(orc, tmp_path, argv_style, use_mss):
+    """`deepgrp [flags] predict model.hdf5 file.fa` -> TSV identical to the reference pipeline run
+    by the oracle on the same probabilities (multi-record FASTA, N flanks, a record shorter than
+    the window, lower-case input)."""
+    from deepgrp_amd.__main__ import main
+    rng = np.random.default_rng(12)
+    T = 30
+    recs = {"chr1 some description": "NNNNN" + "".join(rng.choice(list("ACGT"), size=4000)) + "NN",
+            "short": "".join(rng.choice(list("ACGT"), size=T - 3)),
+            "chr3": "".join(rng.choice(list("acgtn"), size=1500, p=[.23, .23, .23, .23, .08])).strip("n")}
+    fasta = tmp_path / "in.fa"
+    fasta.write_text("".join(f">{h}\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n" for h, s in recs.items()))
+    model_file = os.path.join(GOLDEN, "model_u16_T30_att_vlen.h5")
+    out = tmp_path / "out.tsv"
+    flags = ["-b", "7", "-s", "4", "-x", "5", "-l", "3"]
+    tail = [model_file, str(fasta), "--output", str(out)] + ([] if use_mss else ["-m"])
+    main(flags + (["predict"] if argv_style == "reference" else []) + tail)
+    want = _expected_tsv(orc, str(fasta), model_file, None, 4, 7, 3, 5, use_mss)
+    assert out.read_text() == want
+    assert want.count("\n") > 3
+
+
+def test_trained_synthetic_model_calls_planted_repeats():
+    """The benchmark model (tools/train_synth_model.py) on a fresh synthetic chromosome: most
+    planted repeat bases are called, most background is confident class 0."""
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence
+    w = synthetic.trained_weights()
+    model = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, 200)
+    raw = synthetic.synthetic_chromosome(400_000, contig=5, flank=1000)
+    idx, truth = synthetic.synthetic_truth(400_000, contig=5, flank=1000)
+    st, d_idx = upload_sequence(raw)
+    pipe = ContigPipeline(model)
+    labels = pipe.labels(pipe.merged(d_idx)).cpu().numpy()
+    truth = truth[st:st + labels.size]
+    called = labels > 0
+    assert (called[truth > 0]).mean() > 0.7 and (called[truth == 0]).mean() < 0.2

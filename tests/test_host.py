@@ -1,0 +1,337 @@
+"""Host-side logic that needs no GPU: Options, the HDF5 reader/writer, the CLI surface, the
+FASTA reader, contig sharding and the record gather (gloo, world_size 2), and the C-ABI
+library's symbol table.  Reference tests mirrored where they exist (cited per test)."""
+import io
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+from deepgrp_amd import hdf5, model as dgmodel, synthetic
+from deepgrp_amd.__main__ import CommandLineParser, _read_multi_fasta
+
+_DEFAULTS = {'project_root_dir': '.', 'repeats_to_search': [1, 2, 3, 4], 'vecsize': 150, 'n_epochs': 200,
+             'n_batches': 250, 'early_stopping_th': 10, 'batch_size': 256, 'repeat_probability': 0.3,
+             'optimizer': 'RMSprop', 'learning_rate': 0.001, 'momentum': 0.9, 'rho': 0.9, 'epsilon': 1e-10, 'rnn': 'GRU',
+             'units': 32, 'dropout': 0.25, 'attention': False, 'min_mss_len': 50, 'xdrop_len': 50}
+_CUSTOM = {'project_root_dir': 'test', 'repeats_to_search': [1, 2, 3], 'vecsize': 157, 'n_epochs': 206, 'n_batches': 256,
+           'early_stopping_th': 11, 'batch_size': 259, 'repeat_probability': 0.2, 'optimizer': 'Adam', 'learning_rate': 0.002,
+           'momentum': 0.8, 'rho': 0.8, 'epsilon': 1e-08, 'rnn': 'LSTM', 'units': 326, 'dropout': 0.256, 'attention': True,
+           'min_mss_len': 507, 'xdrop_len': 507, 'some_additional': 'test'}
+_CASES = [({}, _DEFAULTS), (_CUSTOM, _CUSTOM)]
+
+
+class TestOptions:
+    """tests/test_model.py:27-125 of the reference."""
+
+    @pytest.mark.parametrize('init_args, expected', _CASES)
+    def test_init(self, init_args, expected):
+        got = dgmodel.Options(**init_args)
+        for attribute, value in expected.items():
+            assert getattr(got, attribute) == value
+
+    @pytest.mark.parametrize('init_args, expected', _CASES)
+    def test_fromdict_todict(self, init_args, expected):
+        got = dgmodel.Options()
+        got.fromdict(init_args)
+        for attribute, value in expected.items():
+            assert getattr(got, attribute) == value
+        assert dgmodel.Options(**init_args).todict() == expected
+
+    @pytest.mark.parametrize('init_args, expected', _CASES)
+    def test_toml_round_trip(self, init_args, expected, tmp_path):
+        import tomli
+        path = tmp_path.joinpath('testfile.toml')
+        with path.open('w') as file:
+            dgmodel.Options(**init_args).to_toml(file)
+        assert tomli.loads(path.read_text()) == expected
+        got = dgmodel.Options.from_toml(str(path))
+        with path.open() as fh:
+            got2 = dgmodel.Options.from_toml(fh)
+        for attribute, value in expected.items():
+            assert getattr(got, attribute) == value and getattr(got2, attribute) == value
+        with pytest.raises(TypeError):
+            dgmodel.Options.from_toml(3)
+
+    def test_aliases_and_items(self):
+        opt = dgmodel.Options(gru_units=77, gru_dropout=0.5)
+        assert opt.units == 77 and opt.dropout == 0.5 and "gru_units" not in opt.todict()
+        opt["gru_units"] = 5
+        assert opt["units"] == 5 and opt["gru_units"] == 5
+        assert "units" in str(opt)
+
+    def test_defaults_toml_of_the_reference_shape(self):
+        txt = 'vecsize = 342\nunits = 60\nattention = true\nrepeats_to_search = [ 1, 2, 3, 4,]\nrnn = "GRU"\n'
+        opt = dgmodel.Options.from_toml(io.StringIO(txt))
+        assert (opt.vecsize, opt.units, opt.attention, opt.repeats_to_search) == (342, 60, True, [1, 2, 3, 4])
+
+
+def test_get_dna_encoding():
+    """tests/test_model.py:182-184 of the reference."""
+    assert dgmodel._get_dna_encoding() == [3, 2, 1, 0, 4]
+
+
+# ------------------------------------------------------------------------------------------ HDF5
+@pytest.mark.parametrize("name", ["model_u8_T20", "model_u60_T342_att", "model_u16_T30_att_vlen"])
+def test_read_keras_hdf5_written_by_libhdf5(name):
+    """Files produced with h5py/libhdf5 (oracle/make_h5_fixtures.py) through the package's own reader."""
+    w = dgmodel.read_keras_hdf5(os.path.join(GOLDEN, name + ".h5"))
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    for k in ("kernel", "recurrent_kernel", "bias", "ff_kernel", "ff_bias"):
+        np.testing.assert_array_equal(w[k], z[k])
+    assert (w["vecsize"], w["units"], w["classes"], w["attention"]) == (int(z["T"]), int(z["u"]), int(z["C"]), bool(z["attention"]))
+    if w["attention"]:
+        np.testing.assert_array_equal(w["scale"], z["scale"])
+    names = [l["name"] for l in w["config"]["config"]["layers"]]
+    assert names[:3] == ["input_1", "reverse_complement", "BGRU"] and names[-2:] == ["FF", "softmax"]
+
+
+def test_hdf5_generic_access():
+    with hdf5.File(os.path.join(GOLDEN, "model_u8_T20.h5")) as f:
+        assert f.attrs["keras_version"] == b"2.5.0" and f.attrs["backend"] == b"tensorflow"
+        assert set(f.keys()) == {"model_weights", "optimizer_weights"}
+        assert f["model_weights"].attrs["layer_names"][2] == b"BGRU"
+        ds = f["model_weights/BGRU/BGRU/gru_cell/bias:0"]
+        assert ds.is_dataset and ds.read().shape == (2, 24)
+        assert int(f["optimizer_weights/training/RMSprop/iter:0"].read()) == 1234
+        with pytest.raises(KeyError):
+            f["model_weights/nope"]
+    with pytest.raises(hdf5.HDF5Error):
+        hdf5.File(__file__)
+
+
+@pytest.mark.parametrize("attention", [False, True])
+def test_hdf5_writer_round_trip(tmp_path, attention):
+    w = synthetic.synthetic_weights(60, 5, attention, seed=3)
+    path = str(tmp_path / "m.hdf5")
+    dgmodel.save_keras_hdf5(path, w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=342)
+    r = dgmodel.read_keras_hdf5(path)
+    for k in ("kernel", "recurrent_kernel", "bias", "ff_kernel", "ff_bias"):
+        np.testing.assert_array_equal(r[k], w[k])
+    assert (r["vecsize"], r["units"], r["classes"], r["attention"]) == (342, 60, 5, attention)
+    if attention:
+        np.testing.assert_array_equal(r["scale"], w["scale"])
+
+
+def test_model_format_errors(tmp_path):
+    w = hdf5.Writer()
+    w.set_attr("/", "model_config", b'{"class_name": "Functional", "config": {"layers": [{"class_name": "LSTM", "name": "BLSTM", "config": {}}]}}')
+    w.create_group("model_weights")
+    w.save(str(tmp_path / "lstm.h5"))
+    with pytest.raises(dgmodel.ModelFormatError, match="LSTM"):
+        dgmodel.read_keras_hdf5(str(tmp_path / "lstm.h5"))
+    w2 = hdf5.Writer()
+    w2.create_dataset("x", np.arange(3, dtype=np.float32))
+    w2.save(str(tmp_path / "nocfg.h5"))
+    with pytest.raises(dgmodel.ModelFormatError, match="model_config"):
+        dgmodel.read_keras_hdf5(str(tmp_path / "nocfg.h5"))
+
+
+# ------------------------------------------------------------------------------------------ CLI
+class TestCommandLineParser:
+    def test_init(self):
+        """tests/test_main.py:38-45 of the reference."""
+        import argparse
+        parser = CommandLineParser()
+        assert isinstance(parser.parser, argparse.ArgumentParser)
+        assert parser.threads == 1 and not parser.xla and parser.verbose == 0 and parser.args is None
+
+    def test_reference_grammar_and_defaults(self):
+        a = CommandLineParser().parse_args(["predict", "model.hdf5", "a.fa"]).args
+        assert (a.batch_size, a.step_size, a.xdrop_length, a.min_mss_length, a.threads, a.xla, a.verbose) == (256, 50, 50, 50, 1, False, 0)
+        assert (a.model, a.FASTA, a.output, a.no_use_mss) == ("model.hdf5", ["a.fa"], "-", False)
+        a = CommandLineParser().parse_args(["-b", "4", "-s", "10", "-x", "-1", "-l", "3", "-t", "0", "--xla", "-vv", "predict", "m", "a", "b",
+                                            "--output", "o.tsv", "-m"]).args
+        assert (a.batch_size, a.step_size, a.xdrop_length, a.min_mss_length, a.threads, a.xla, a.verbose) == (4, 10, -1, 3, 0, True, 2)
+        assert (a.FASTA, a.output, a.no_use_mss) == (["a", "b"], "o.tsv", True)
+
+    def test_readme_grammar(self):
+        """README.rst:94 `deepgrp <modelfile> <fastafile>`."""
+        a = CommandLineParser().parse_args(["-b", "8", "model.hdf5", "x.fa", "-"]).args
+        assert (a.command, a.model, a.FASTA, a.batch_size) == ("predict", "model.hdf5", ["x.fa", "-"], 8)
+
+    def test_train_is_refused(self):
+        p = CommandLineParser().parse_args(["train", "p.toml", "a.npz", "b.npz", "c.bed"])
+        with pytest.raises(SystemExit):
+            p.run()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_read_multi_fasta(tmp_path, n):
+    """tests/test_main.py:241-250 of the reference."""
+    rng = np.random.default_rng(n)
+    sequences = {f"chr{i+1}": "".join(rng.choice(["N", "A", "C", "G", "T"], size=100)) for i in range(n)}
+    path = tmp_path / "chr_dummy.fa"
+    path.write_text("\n".join(f">{h}\n{s}" for h, s in sequences.items()))
+    with path.open() as fh:
+        assert dict(_read_multi_fasta(fh)) == sequences
+
+
+def test_read_multi_fasta_quirks():
+    txt = ["ACGT\n", ">chr1 desc\n", "acgt\n", "NNa\n", ">chr2\n", ">chr3\n", "tt\n"]
+    assert list(_read_multi_fasta(txt)) == [("chr1 desc", "ACGTNNA"), ("chr3", "TT")] or \
+        list(_read_multi_fasta(txt)) == [("chr1 desc", "ACGTNNA"), ("chr2", ""), ("chr3", "TT")]
+    with pytest.raises(IndexError):
+        list(_read_multi_fasta([">a\n", "\n"]))
+
+
+def test_read_multi_fasta_matches_oracle(orc):
+    txt = ["ACGT\n", ">chr1 desc\n", "acgt\n", "NNa\n", ">chr2\n", ">chr3\n", "tt\n", ">\n", "AC\n"]
+    assert list(_read_multi_fasta(txt)) == orc.read_multi_fasta(txt)
+
+
+# ------------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from deepgrp_amd import _lib
+    header = open(os.path.join(ROOT, "include", "deepgrp_hip.h")).read()
+    declared = set(re.findall(r"\b(dgrp_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/deepgrp_hip.h but not exported"
+    assert declared == set(_lib.exported_symbols())
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (dgrp_[a-z0-9_]+)", nm))
+    assert exported == declared
+    assert L.dgrp_abi_version() == 1
+    assert L.dgrp_window_count(1000, 200, 50) == 16 and L.dgrp_window_count(200, 200, 50) == 0
+
+
+def test_host_only_entry_points():
+    import ctypes as C
+    from deepgrp_amd import _lib
+    L = _lib.lib()
+    st, kept = C.c_int64(), C.c_int64()
+    raw = np.frombuffer(b"NNACGTNANN", np.uint8)
+    assert L.dgrp_strip_n(raw.ctypes.data_as(C.c_void_p), raw.size, C.byref(st), C.byref(kept)) == 0
+    assert (st.value, kept.value) == (2, 6)
+    raw = np.frombuffer(b"NNNN", np.uint8)
+    L.dgrp_strip_n(raw.ctypes.data_as(C.c_void_p), raw.size, C.byref(st), C.byref(kept))
+    assert kept.value < 0
+    assert L.dgrp_mss_workspace_bytes(1000) > 0 and L.dgrp_segments_workspace_bytes(1000) > 0
+    # argument errors come back as codes with a message, not crashes
+    assert L.dgrp_scores(None, 10, 99, None, None, None) == -1
+    assert b"bad n/C" in L.dgrp_last_error()
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path raises instead of computing on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from deepgrp_amd import pipeline, sequence, mss, prediction
+    w = synthetic.synthetic_weights(8, 5, False)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pipeline.DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, 20)
+    with pytest.raises(RuntimeError):
+        sequence.one_hot_encode_dna_sequence("ACGT")
+    with pytest.raises(RuntimeError):
+        mss.find_mss_labels(np.ones(4), np.ones(4, np.int64), 3, 0, 0)
+    with pytest.raises(RuntimeError):
+        prediction.apply_mss(np.ones((4, 5), np.float32), dgmodel.Options())
+
+
+def test_product_never_touches_the_oracle():
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "deepgrp_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in txt.lower() or fn == "Makefile" and False, f"{fn} mentions the oracle"
+
+
+# ------------------------------------------------------------------------------------------ multi-GPU host logic
+def test_shard_contigs():
+    from deepgrp_amd.distributed import shard_contigs
+    lengths = [250, 10, 240, 30, 100, 100, 5, 90]
+    for world in (1, 2, 3, 8, 16):
+        parts = shard_contigs(lengths, world)
+        assert len(parts) == world and sorted(i for p in parts for i in p) == list(range(len(lengths)))
+        loads = [sum(lengths[i] for i in p) for p in parts]
+        assert max(loads) <= max(max(lengths), -(-sum(lengths) // world) + max(lengths) // 2 + 60)
+    assert shard_contigs([5, 5, 5, 5], 2) == [[0, 2], [1, 3]]
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deepgrp_amd.distributed import predict_records_sharded
+    from deepgrp_amd.pipeline import SEGMENT_DTYPE
+    records = [(f"chr{i}", "A" * n) for i, n in enumerate([50, 10, 40, 30, 5])]
+
+    def run_one(seq, idx):                      # stands in for the device pipeline: 2 rows per record
+        rows = np.zeros(2 if len(seq) > 5 else 0, SEGMENT_DTYPE)
+        for j in range(rows.shape[0]):
+            rows[j] = (j * 7 + idx, j * 7 + idx + len(seq), 1 + j, idx)
+        return rows
+
+    out = predict_records_sharded(records, run_one, torch.device("cpu"))
+    q.put((rank, out.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_records_gloo_world2():
+    """N > 1 path on CPU: contig sharding + the record gather, world_size 2 over gloo."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] == []
+    rows = got[0]
+    assert [r[3] for r in rows] == [0, 0, 1, 1, 2, 2, 3, 3]          # ordered by record, record 4 contributed none
+    assert rows[0] == (0, 50, 1, 0) and rows[3] == (8, 18, 2, 1)
+
+
+def test_synthetic_inputs_are_deterministic():
+    a = synthetic.synthetic_chromosome(50_000, contig=3)
+    assert a == synthetic.synthetic_chromosome(50_000, contig=3) and a != synthetic.synthetic_chromosome(50_000, contig=4)
+    assert a[:10_000] == b"N" * 10_000 and a[-10_000:] == b"N" * 10_000 and set(a) <= set(b"ACGTN")
+    idx, truth = synthetic.synthetic_truth(50_000, contig=3)
+    assert idx.shape == truth.shape == (50_000,) and truth.max() <= 4 and (truth > 0).mean() > 0.05
+    w = synthetic.trained_weights()
+    assert w["kernel"].shape == (5, 384) and w["recurrent_kernel"].shape == (128, 384) and w["ff_kernel"].shape == (128, 5)
+
+
+@pytest.mark.parametrize("begin", (3, 5, 50))
+@pytest.mark.parametrize("startpos", [0, 10, 22, 33])
+@pytest.mark.parametrize("endpos", [0, 44, 54, 62])
+@pytest.mark.parametrize("label", [1, 2, 3])
+def test_get_segments_reference_test(begin, startpos, endpos, label):
+    """tests/test_sequence.py:30-44 of the reference on the package's host mirror."""
+    from deepgrp_amd import sequence as dgseq
+    data = np.zeros(100, dtype=np.int64)
+    if endpos > 0:
+        data[startpos:endpos] = label
+    st, en, lb = dgseq.get_segments(data, begin)
+    assert st == (max(startpos, begin) if endpos > begin else 99)
+    assert en == (endpos if endpos > begin else 100)
+    assert lb == (label if endpos > begin else 0)
+
+
+def test_get_segments_walk_matches_golden(orc):
+    from conftest import golden
+    from deepgrp_amd import sequence as dgseq
+    g = golden("segments.npz")
+    for k in range(int(g["count"])):
+        lab = g[f"lab{k}"]
+        i, walked = 0, []
+        while i < lab.size:
+            st, en, lb = dgseq.get_segments(lab, i)
+            assert (st, en, lb) == orc.get_segments(lab, i)
+            i = en
+            walked.append((st + 5, en + 5, lb))
+        np.testing.assert_array_equal(np.array(walked, np.int64).reshape(-1, 3), g[f"all{k}"])
