@@ -60,8 +60,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mbp", type=float, default=50.0, help="chromosome size per GPU in Mbp (configs[1] = 50)")
-    ap.add_argument("--gain", type=float, default=3.0, help="weight scale of the synthetic model (3 = structured set)")
-    ap.add_argument("--bias0", type=float, default=0.0, help="added to the background class's dense bias")
+    ap.add_argument("--weights", choices=("trained", "random"), default="trained",
+                    help="trained: deepgrp_amd/data/synthetic_gru128.npz (fitted to the planted repeats, genome-like output); "
+                         "random: Keras initialisers scaled by --gain (stationary noise, the MSS worst case)")
+    ap.add_argument("--gain", type=float, default=3.0, help="weight scale of the random model")
     ap.add_argument("--cpu-sample-bp", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -79,8 +81,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    weights = synthetic.synthetic_weights(UNITS, CLASSES, attention=False, seed=7, gain=args.gain)
-    weights["ff_bias"][0] += args.bias0
+    if args.weights == "trained":
+        weights = synthetic.trained_weights()
+        wdesc = "synthetic model fitted to the planted tandem repeats (tools/train_synth_model.py)"
+    else:
+        weights = synthetic.synthetic_weights(UNITS, CLASSES, attention=False, seed=7, gain=args.gain)
+        wdesc = f"random-init weights gain={args.gain:g}"
     model = DeviceModel(weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
                         weights["ff_bias"], weights["scale"], vecsize=T)
     pipe = ContigPipeline(model, STEP, BATCH, MIN_MSS, XDROP, use_mss=True)
@@ -133,7 +139,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.mbp:g} Mbp synthetic chromosome per GPU (BASELINE configs[1]), "
                                    f"window={T} stride={STEP} hidden={UNITS} {CLASSES}-class, batch_size={BATCH}, "
-                                   f"MSS min_len={MIN_MSS} xdrop={XDROP}, random-init weights gain={args.gain:g}",
+                                   f"MSS min_len={MIN_MSS} xdrop={XDROP}, {wdesc}",
                        "rows_out": int(nrows), "parallelism": f"contig-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,

@@ -98,11 +98,14 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
             const int unit = 32 * w + (l & 31);
             const bool uok = unit < u;
             for (int g = 0; g < 3; ++g) {
+                // exp2-domain scale folded into the weights: sigmoid(x) = 1/(1 + 2^(-x log2 e)) for z and r,
+                // tanh(x) = 1 - 2/(1 + 2^(2 x log2 e)) for the candidate (gru_kernel.hip)
+                const float gs = g < 2 ? -1.4426950408889634f : 2.8853900817779268f;
                 // recurrent part: k-steps 0..KS-1
                 for (int ks = 0; ks < KS; ++ks)
                     for (int j = 0; j < 8; ++j) {
                         const int k = 16 * ks + 8 * (l >> 5) + j;
-                        at(w, g * (KS + 1) + ks, l, j) = (uok && k < u) ? f2h(rec[(size_t)k * u3 + g * u + unit]) : 0;
+                        at(w, g * (KS + 1) + ks, l, j) = (uok && k < u) ? f2h(gs * rec[(size_t)k * u3 + g * u + unit]) : 0;
                     }
                 // input part (k-step KS): rows 0-4 kernel hi, 5 bias hi | rows 8-12 kernel lo, 13 bias lo.
                 // z and r carry the whole input projection and both biases; the h gate's fragment only
@@ -114,6 +117,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
                         else if (j == 5) v = g < 2 ? (float)((double)bias[g * u + unit] + (double)bias[u3 + g * u + unit])
                                                    : bias[u3 + 2 * u + unit];
                     }
+                    v *= gs;
                     const uint16_t hi = f2h(v);
                     at(w, g * (KS + 1) + KS, l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
                 }
@@ -124,6 +128,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
                     if (j < 5) v = kernel[(size_t)j * u3 + 2 * u + unit];
                     else if (j == 5) v = bias[2 * u + unit];
                 }
+                v *= 2.8853900817779268f;
                 const uint16_t hi = f2h(v);
                 at(w, 3 * (KS + 1), l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
             }

@@ -49,13 +49,26 @@ struct gru_params {
     int ospan;            // rows of the LDS output image (mode 0), 0 = none
 };
 
-__device__ __forceinline__ float fast_sigmoid(float x)
+// The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
+// so the accumulators feed v_exp_f32 directly:  sigmoid(x) = 1/(1 + 2^(-x log2 e)),
+// tanh(x) = 1 - 2/(1 + 2^(2 x log2 e)).
+__device__ __forceinline__ float sigmoid_from_scaled(float a) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
+__device__ __forceinline__ float tanh_from_scaled(float a) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
+__device__ __forceinline__ float fast_tanh(float x) { return tanh_from_scaled(2.8853900817779268f * x); }
+
+// rotate within each row of 16 lanes (DPP row_ror): an all-reduce over the 16 class lanes in 4 steps
+template <int N>
+__device__ __forceinline__ float row_ror(float x)
 {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 | N, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float fast_tanh(float x)
+__device__ __forceinline__ float row_allmax(float x)
 {
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+    x = fmaxf(x, row_ror<8>(x)); x = fmaxf(x, row_ror<4>(x)); x = fmaxf(x, row_ror<2>(x)); return fmaxf(x, row_ror<1>(x));
+}
+__device__ __forceinline__ float row_allsum(float x)
+{
+    x += row_ror<8>(x); x += row_ror<4>(x); x += row_ror<2>(x); return x + row_ror<1>(x);
 }
 
 // LDS carve (bytes) -- shared by host and device
@@ -64,13 +77,13 @@ __host__ __device__ static inline int gru_lds_dpart(int NW) { return 2 * NW * 64
 __host__ __device__ static inline int gru_lds_seq(int Tp) { return DGRP_WG_WINDOWS * Tp; }
 __host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 8 + DGRP_WG_WINDOWS * 4; }
 
-template <int NW>
+template <int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params p)
 {
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;   // HS: padded row pitch (halves) -> conflict-free b128 reads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *hbuf = reinterpret_cast<_Float16 *>(smem);
-    f32x4 *dpart = reinterpret_cast<f32x4 *>(smem + gru_lds_hbuf(UP));
+    float *dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP));       // [2][4 regs][NW][64]
     uint8_t *seqs = smem + gru_lds_hbuf(UP) + gru_lds_dpart(NW);
     int64_t *row0s = reinterpret_cast<int64_t *>(seqs + gru_lds_seq(p.Tp));
     int *rowoff = reinterpret_cast<int *>(row0s + DGRP_WG_WINDOWS);
@@ -104,9 +117,9 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     }
     for (int i = tid; i < 32 * HS; i += 64 * NW) hbuf[i] = (_Float16)0.0f;          // h_{-1} = 0
     int64_t lo = 0;
-    if (p.mode == 0) {
-        // smallest placement row of the workgroup; with the partial-batch shift the order of rows
-        // is still monotone inside each of the two regimes, so min is at one of the two ends
+    if (MODE == 0) {
+        // smallest placement row of the two ends (the partial-batch shift keeps rows monotone inside
+        // each regime); windows that fall outside [lo, lo + ospan) go to HBM directly
         int64_t a = dgrp_place_row(p.place, wg_w, p.s), b = dgrp_place_row(p.place, wg_w + nvalid - 1, p.s);
         lo = a < b ? a : b;
         for (int i = tid; i < p.ospan * C; i += 64 * NW) obuf[i] = 0u;
@@ -115,8 +128,8 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         int64_t r0 = -1;
         int off = -1;
         if (tid < nvalid) {
-            r0 = p.mode == 0 ? dgrp_place_row(p.place, wg_w + tid, p.s) : (wg_w + tid - p.w0) * (int64_t)T;
-            if (p.mode == 0 && r0 - lo + T <= p.ospan) off = (int)(r0 - lo);
+            r0 = MODE == 0 ? dgrp_place_row(p.place, wg_w + tid, p.s) : (wg_w + tid - p.w0) * (int64_t)T;
+            if (MODE == 0 && r0 >= lo && r0 - lo + T <= p.ospan) off = (int)(r0 - lo);
         }
         row0s[tid] = r0;
         rowoff[tid] = off;
@@ -136,47 +149,45 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     _Float16 *hcur = hbuf, *hnxt = hbuf + 32 * HS;
     const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     const f32x4 zero4 = { 0, 0, 0, 0 };
+    const int cls = lane & 15;
+    const float fbias = cls < C ? p.ffb[cls] : 0.0f;
 
-    // softmax + merge of step `t`'s partial logits (run by one wave after the step's barrier)
+    // Softmax + merge of step t's partial logits.  The 16x16 logit tile (window = 4*(lane>>4) + reg,
+    // class = lane & 15) is split by accumulator register over the waves, one value per lane.
     auto finish_step = [&](int t) {
-        const f32x4 *dp = dpart + (size_t)(t & 1) * NW * 64 + lane;
-        f32x4 sum = dp[0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) sum += dp[w * 64];
-        const int c = lane & 15;
-        const float bias = c < C ? p.ffb[c] : 0.0f;
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
+            if (reg % NW != wave) continue;
+            const float *dp = dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
+            float sum = dp[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sum += dp[w * 64];
             const int wi = 4 * (lane >> 4) + reg;
-            float lg = c < C ? sum[reg] + bias : -INFINITY;
-            float val;
-            if (p.mode == 2) {
-                val = lg;                                     // attention: softmax happens later
-            } else {
-                float m = lg;
-                m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
-                m = fmaxf(m, __shfl_xor(m, 4)); m = fmaxf(m, __shfl_xor(m, 8));
-                float e = c < C ? __expf(lg - m) : 0.0f;
-                float ssum = e;
-                ssum += __shfl_xor(ssum, 1); ssum += __shfl_xor(ssum, 2);
-                ssum += __shfl_xor(ssum, 4); ssum += __shfl_xor(ssum, 8);
-                val = e / ssum;
+            const float lg = cls < C ? sum + fbias : -INFINITY;
+            float val = lg;
+            if (MODE != 2) {                                  // attention: softmax happens in the second kernel
+                const float m = row_allmax(lg);
+                const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg - m));   // 0 for the padding lanes
+                val = e * __builtin_amdgcn_rcpf(row_allsum(e));
             }
-            const int64_t r0 = row0s[wi];
-            if (c < C && r0 >= 0) {
-                if (p.mode == 0) {
+            if (cls < C && wi < nvalid) {
+                if (MODE == 0) {
                     const int off = rowoff[wi];
-                    if (off >= 0) atomicMax(&obuf[(off + t) * C + c], __float_as_uint(val));
-                    else if (r0 + t < p.n) atomicMax(reinterpret_cast<unsigned *>(p.out) + (r0 + t) * C + c, __float_as_uint(val));
+                    if (off >= 0) {
+                        atomicMax(&obuf[(off + t) * C + cls], __float_as_uint(val));
+                    } else {
+                        const int64_t row = row0s[wi] + t;
+                        if (row < p.n) atomicMax(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
+                    }
                 } else {
-                    p.out[(r0 + t) * C + c] = val;
+                    p.out[(row0s[wi] + t) * C + cls] = val;
                 }
             }
         }
     };
 
     for (int t = 0; t < T; ++t) {
-        if (t > 0 && wave == (t - 1) % NW) finish_step(t - 1);
+        if (t > 0) finish_step(t - 1);
 
         // ---- A operand of the input k-step: one-hot(base) | 1 ------------------------------
         uint32_t b = myseq[dir ? T - 1 - t : t];
@@ -186,9 +197,9 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         const uint4 xu = make_uint4(sel == 0 ? one : 0u, sel == 1 ? one : 0u, (sel == 2 ? one : 0u) | 0x3C000000u, 0u);
         const half8 xa = __builtin_bit_cast(half8, xu);
 
-        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bz[KS], zero16, 0, 0, 0);
         f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Br[KS], zero16, 0, 0, 0);
         f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bg[KS], zero16, 0, 0, 0);
+        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bz[KS], zero16, 0, 0, 0);
         const _Float16 *arow = hcur + r * HS + 8 * khalf;
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
@@ -197,15 +208,15 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bg[k], ag, 0, 0, 0);
             az = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bz[k], az, 0, 0, 0);
         }
-        // ---- gates (Keras GRUCell, reset_after=True) ---------------------------------------
+        // ---- gates (Keras GRUCell, reset_after=True), accumulators are in the exp2 domain -----
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ag[i] *= fast_sigmoid(ar[i]);          // r * (h.U_h + b_rec_h)
+        for (int i = 0; i < 16; ++i) ag[i] *= sigmoid_from_scaled(ar[i]);     // r * (h.U_h + b_rec_h)
         ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bxh, ag, 0, 0, 0);    // + x.W_h + b_in_h
 #pragma unroll
-        for (int i = 0; i < 16; ++i) az[i] = fast_sigmoid(az[i]);
+        for (int i = 0; i < 16; ++i) az[i] = sigmoid_from_scaled(az[i]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float hh = fast_tanh(ag[i]);
+            const float hh = tanh_from_scaled(ag[i]);
             h[i] = hh + az[i] * (h[i] - hh);                                 // z*h + (1-z)*hh
         }
         // ---- publish h_t (fp16) for the next step's A operand ------------------------------
@@ -215,7 +226,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             const int row = (i & 3) + 8 * (i >> 2) + 4 * khalf;            // 32x32 C/D layout
             wcol[row * HS] = (_Float16)h[i];
         }
-        if (p.mode == 2) {
+        if (MODE == 2) {
             // attention: keep avg[t] (fp32) for the second kernel
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -233,14 +244,16 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
             d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
-            dpart[(size_t)(t & 1) * NW * 64 + wave * 64 + lane] = d;
+            float *dw = dpart + ((size_t)(t & 1) * 4 * NW + wave) * 64 + lane;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) dw[reg * NW * 64] = d[reg];
         }
         __syncthreads();
         _Float16 *tmp = hcur; hcur = hnxt; hnxt = tmp;
     }
-    if (wave == (T - 1) % NW) finish_step(T - 1);
+    finish_step(T - 1);
 
-    if (p.mode == 0 && p.ospan > 0) {
+    if (MODE == 0 && p.ospan > 0) {
         __syncthreads();
         // flush the pre-merged image: contiguous rows -> 256-byte atomic wave-instructions
         unsigned *gout = reinterpret_cast<unsigned *>(p.out) + lo * C;
@@ -342,13 +355,27 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
 }
 
 // ------------------------------------------------------------------------------------------
+template <int NW, int MODE>
+static int launch_gru_mode(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
+{
+    static bool configured = false;          // per instantiation; the attribute is per function, not per launch
+    if (!configured) {
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_fused_kernel<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gru_fused_kernel<NW, MODE>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
 template <int NW>
 static int launch_gru(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
-    DGRP_HIP(hipFuncSetAttribute((const void *)gru_fused_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(gru_fused_kernel<NW>, dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
-    DGRP_LAUNCH_CHECK();
-    return DGRP_OK;
+    switch (p.mode) {
+    case 0: return launch_gru_mode<NW, 0>(p, groups, lds, stream);
+    case 1: return launch_gru_mode<NW, 1>(p, groups, lds, stream);
+    default: return launch_gru_mode<NW, 2>(p, groups, lds, stream);
+    }
 }
 
 int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
