@@ -129,6 +129,14 @@ def main():
     avg_ms = float(np.mean(kern_ms))
     achieved = float(np.mean(kern_windows)) * FLOP_PER_WINDOW / (avg_ms * 1e-3) / 1e12
 
+    # HBM traffic of that kernel from the PMC passes of profiles/ (separate rocprofv3 --pmc runs of this
+    # command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this launch size
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_gru_traffic.json")
+    if os.path.exists(tpath) and args.weights == "trained":
+        with open(tpath) as fh:
+            traffic = round(json.load(fh)["hbm_bytes_per_window"] * float(np.mean(kern_windows)))
+
     if rank == 0:
         value = n_bases * world * args.steps / dt / 1e6
         out = {
@@ -142,8 +150,8 @@ def main():
                                    f"MSS min_len={MIN_MSS} xdrop={XDROP}, {wdesc}",
                        "rows_out": int(nrows), "parallelism": f"contig-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "gru_fused_kernel<4>", "avg_launch_ms": round(avg_ms, 3),
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "kernel": "gru_fused_kernel<4,0>", "flop_per_window": FLOP_PER_WINDOW, "avg_launch_ms": round(avg_ms, 3),
                          "windows_per_launch": int(np.mean(kern_windows)), "launches_timed": len(kern_ms)},
         }
         if not args.no_cpu_baseline:
