@@ -33,6 +33,8 @@ def gather_records(local: np.ndarray, device: torch.device) -> np.ndarray:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return np.sort(local, order=["contig", "start"])
     world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "gloo":
+        device = torch.device("cpu")               # gloo has no GPU all_gather; RCCL ("nccl") takes HBM tensors
     cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(counts, cnt)
