@@ -75,7 +75,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     DGRP_REQUIRE(out, "dgrp_model_create: NULL out");
     *out = nullptr;
     DGRP_REQUIRE(T >= 1 && T <= 65535, "dgrp_model_create: window size %d out of range", T);
-    DGRP_REQUIRE(u >= 1 && u <= 128, "dgrp_model_create: units=%d not supported (1..128)", u);
+    DGRP_REQUIRE(u >= 1 && u <= 256, "dgrp_model_create: units=%d not supported (1..256)", u);
     DGRP_REQUIRE(C >= 2 && C <= 16, "dgrp_model_create: classes=%d not supported (2..16)", C);
     DGRP_REQUIRE(kernel && rec && bias && ffk && ffb && (!attention || scale), "dgrp_model_create: NULL tensor");
     char nm[8];

@@ -81,6 +81,9 @@ template <int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params p)
 {
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;   // HS: padded row pitch (halves) -> conflict-free b128 reads
+    // u > 128: the three gate slices no longer fit 256 VGPRs; the z gate's fragments (needed last in a
+    // step) are then re-read from L2 every step (16 KB per wave-step, a few % of L2 bandwidth)
+    constexpr bool ZSTREAM = NW > 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     _Float16 *hbuf = reinterpret_cast<_Float16 *>(smem);
     float *dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP));       // [2][4 regs][NW][64]
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 #pragma unroll
     for (int k = 0; k <= KS; ++k) {
         uint4 a = mypack[(size_t)(k) * 64], b = mypack[(size_t)(KS + 1 + k) * 64], c = mypack[(size_t)(2 * (KS + 1) + k) * 64];
-        Bz[k] = __builtin_bit_cast(half8, a);
+        if (!ZSTREAM || k == KS) Bz[k] = __builtin_bit_cast(half8, a);
         Br[k] = __builtin_bit_cast(half8, b);
         Bg[k] = __builtin_bit_cast(half8, c);
     }
@@ -206,7 +209,8 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             const half8 a = *reinterpret_cast<const half8 *>(arow + 16 * k);
             ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Br[k], ar, 0, 0, 0);
             ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bg[k], ag, 0, 0, 0);
-            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bz[k], az, 0, 0, 0);
+            const half8 bz = ZSTREAM ? __builtin_bit_cast(half8, mypack[(size_t)k * 64]) : Bz[k];
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bz, az, 0, 0, 0);
         }
         // ---- gates (Keras GRUCell, reset_after=True), accumulators are in the exp2 domain -----
 #pragma unroll
@@ -392,7 +396,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     if (mode == 0) {
         // rows spanned by 16 consecutive windows, capped so that two workgroups fit a CU's 160 KiB
         const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
-        const int64_t cap = (72 * 1024 - fixed) / (m->C * 4);
+        const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed) / (m->C * 4);   // NW > 4: one workgroup per CU anyway
         p.ospan = (int)(want < cap ? want : cap);
         if (p.ospan < m->T) p.ospan = 0;
     }
@@ -404,8 +408,12 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     case 2: return launch_gru<2>(p, groups, lds, stream);
     case 3: return launch_gru<3>(p, groups, lds, stream);
     case 4: return launch_gru<4>(p, groups, lds, stream);
+    case 5: return launch_gru<5>(p, groups, lds, stream);
+    case 6: return launch_gru<6>(p, groups, lds, stream);
+    case 7: return launch_gru<7>(p, groups, lds, stream);
+    case 8: return launch_gru<8>(p, groups, lds, stream);
     default:
-        dgrp_set_error("units=%d not supported by the register-resident GRU kernel (max 128)", m->u);
+        dgrp_set_error("units=%d not supported by the GRU kernel (max 256)", m->u);
         return DGRP_EINVAL;
     }
 }

@@ -123,6 +123,7 @@ FORWARD_CASES = [
     (128, 200, False, 1.0, 50, 70), (128, 200, False, 3.0, 50, 40), (128, 40, True, 1.5, 7, 33),
     (60, 342, True, 1.0, 50, 20), (64, 30, False, 2.0, 4, 50), (32, 50, True, 1.0, 5, 17),
     (96, 25, False, 1.0, 3, 35), (8, 20, True, 1.0, 2, 19), (100, 64, False, 1.5, 16, 16),
+    (256, 60, False, 1.0, 25, 40), (256, 500, True, 1.5, 25, 19), (160, 40, True, 1.0, 9, 33), (200, 30, False, 2.0, 5, 17),
 ]
 
 
@@ -157,7 +158,8 @@ def test_predict_on_batch_keras_style(dev, orc):
 @pytest.mark.parametrize("N,T,s,B,u,attention", [(1050, 200, 50, 4, 128, False), (1001, 200, 50, 5, 64, False),
                                                   (5000, 200, 50, 7, 128, False), (5000, 200, 50, 256, 128, False),
                                                   (777, 30, 4, 10, 32, True), (200, 200, 50, 4, 32, False),
-                                                  (201, 200, 50, 4, 32, False), (3000, 100, 300, 3, 32, False)])
+                                                  (201, 200, 50, 4, 32, False), (3000, 100, 300, 3, 32, False),
+                                                  (3000, 500, 25, 256, 256, True)])
 def test_forward_merge_placement_exact(dev, orc, L, N, T, s, B, u, attention):
     """The fused max-merge must equal get_max applied batch by batch to the SAME probabilities
     (bit for bit), incl. the partial-last-batch offset, and be within 1e-3 of the
