@@ -1,0 +1,105 @@
+"""BASELINE.json configurations as parity cases: cfg1 (1 Mbp, defaults.toml model) against the
+full CPU oracle, and cfg2-size runs checked through exact post-processing parity plus
+size-independent properties of the merged array and the segment list."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from deepgrp_amd import synthetic                                    # noqa: E402
+from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence   # noqa: E402
+
+
+def _rows3(rows):
+    return np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3)
+
+
+def test_cfg1_defaults_model_1mbp_vs_full_oracle(orc):
+    """configs[0]: 1 Mbp random-ACGTN FASTA, defaults.toml model (T=342, u=60, attention) -- the whole
+    path on the CPU oracle (float32 NN like TF) next to the GPU: probabilities within 1e-3, and the
+    TSV rows identical once the oracle post-processes the GPU's probabilities."""
+    T, u, s, B = 342, 60, 50, 256
+    w = orc.Weights.random(u, 5, T, True, seed=11, gain=2.0)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    seq = synthetic.synthetic_chromosome(1_000_000, contig=7).decode()
+    pipe = ContigPipeline(dm, s, B, 50, 50, True)
+    st, d_idx = upload_sequence(seq.encode())
+    idx = d_idx.cpu().numpy()
+    n = idx.size
+    nwin = orc.window_count(n, T, s)
+    merged = pipe.merged(d_idx)
+    ref_probs = orc.nn_forward(idx, w, s, 0, nwin, np.float32)
+    ref_merged = orc.merge_all(ref_probs, n, s, B)
+    assert np.abs(merged.cpu().numpy() - ref_merged).max() < 1e-3
+    rows = pipe.segments(pipe.labels(merged), st)
+    probs = dm.forward_windows(d_idx, s, 0, nwin).cpu().numpy()
+    want = orc.predict_contig(seq, lambda _i: (lambda a, b: probs[a:a + b]), T, 5, s, B, 50, 50, True)
+    np.testing.assert_array_equal(_rows3(rows), want)
+    dm.close()
+
+
+@pytest.fixture(scope="module")
+def trained():
+    w = synthetic.trained_weights()
+    dm = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, 200)
+    yield dm
+    dm.close()
+
+
+def test_20mbp_postprocessing_exact(orc, trained):
+    """Scores, classes, labels and rows of a 20 Mbp record: the GPU path against the sequential
+    oracle on the same merged probabilities (thousands of independently scanned stretches)."""
+    raw = synthetic.synthetic_chromosome(20_000_000, contig=3)
+    st, d_idx = upload_sequence(raw)
+    pipe = ContigPipeline(trained)
+    merged = pipe.merged(d_idx)
+    labels = pipe.labels(merged)
+    rows = pipe.segments(labels, st)
+    m = merged.cpu().numpy()
+    sc, cl = orc.scores(m)
+    lab = orc.find_mss_labels(sc, cl, 5, 50, 50)
+    np.testing.assert_array_equal(labels.cpu().numpy(), lab)
+    np.testing.assert_array_equal(_rows3(rows), orc.segments(lab, st))
+
+
+def test_50mbp_properties(trained):
+    """configs[1] size: properties that hold for any input."""
+    T, s, C = 200, 50, 5
+    raw = synthetic.synthetic_chromosome(50_000_000, contig=0)
+    st, d_idx = upload_sequence(raw)
+    n = d_idx.numel()
+    assert st == 10_000 and n == 50_000_000 - 20_000
+    pipe = ContigPipeline(trained)
+    merged = pipe.merged(d_idx)
+    # chunking the windows differently must not change a bit (max is order independent)
+    merged2 = ContigPipeline(trained, chunk_windows=77_776).merged(d_idx)
+    assert torch.equal(merged, merged2)
+    nwin = len(range(0, n - T, s))
+    covered = (nwin // 256 * 256 - 1) * s + T                  # full batches sit where they belong
+    assert float(merged[:covered].max(dim=1).values.min()) >= 1.0 / C - 1e-6       # a softmax row's max
+    assert float(merged[:covered].sum(dim=1).min()) >= 1.0 - 1e-5                  # sum_c max_w >= max_w sum_c
+    assert float(merged.max()) <= 1.0 + 1e-6 and float(merged.min()) >= 0.0
+    last_placed = max((nwin // 256 * (nwin % 256) + (nwin % 256) - 1) * s + T, covered)
+    assert float(merged[last_placed:].abs().max()) == 0.0                           # never-written tail stays zero
+    labels = pipe.labels(merged)
+    assert int(labels.min()) >= 0 and int(labels.max()) < C
+    rows = pipe.segments(labels, st)
+    assert (rows["start"] < rows["end"]).all() and (rows["start"][1:] >= rows["end"][:-1]).all()
+    assert rows["start"].min() >= st and rows["end"].max() <= st + n and (rows["label"] > 0).all()
+    # independent run-length encoding on the host (numpy) of the same labels
+    lab = labels.cpu().numpy()
+    body = lab[:-1]
+    change = np.flatnonzero(np.diff(body) != 0) + 1
+    starts = np.concatenate([[0], change])
+    ends = np.concatenate([change, [body.size]])
+    keep = body[starts] > 0
+    want = np.stack([starts[keep] + st, ends[keep] + st, body[starts[keep]]], 1)
+    if lab[-1] > 0:
+        want = np.concatenate([want, [[n - 1 + st, n + st, lab[-1]]]])
+    np.testing.assert_array_equal(_rows3(rows), want)
+    # MSS only ever relabels zeros inside kept segments
+    sc = torch.empty(n, dtype=torch.float64, device=merged.device)
+    cls = merged.argmax(dim=1)
+    changed = labels.long() != cls
+    assert bool((cls[changed] == 0).all())
