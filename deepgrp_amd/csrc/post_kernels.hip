@@ -368,6 +368,14 @@ __device__ __forceinline__ int wave_max(int v)
     return v;
 }
 
+// value of lane `l` (wave-uniform index) in every lane: v_readlane, no LDS round trip
+__device__ __forceinline__ double lane_value(double x, int l)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)b, l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // One wave per 64-block: statistics used for cutting (1) and skipping (3).
 __global__ void __launch_bounds__(256) mss_blockstat_kernel(const double *__restrict__ S, int64_t n,
                                                             uint64_t *__restrict__ blk, double *__restrict__ blk_sum,
@@ -475,8 +483,8 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                                                       const int32_t *__restrict__ sup_q, const uint8_t *__restrict__ sup_flags,
                                                       int have_stats)
 {
-    __shared__ double sL[MSS_LCAP], sR[MSS_LCAP];
-    __shared__ int32_t sSt[MSS_LCAP], sEn[MSS_LCAP], sPre[MSS_LCAP];
+    __shared__ double2 sLR[MSS_LCAP];                           // (L, R)
+    __shared__ int4 sIdx[MSS_LCAP];                             // (st, en, pre, -)
     const int lane = threadIdx.x;
     const int64_t k = blockIdx.x;
     const int64_t begin = ustart[k], end = ustart[k + 1];
@@ -489,11 +497,19 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
     int64_t run_st = 0;
     double run_L = 0.0;
 
-    auto getL = [&](int64_t j) -> double { return j < MSS_LCAP ? sL[j] : ovf[j - MSS_LCAP].L; };
-    auto getR = [&](int64_t j) -> double { return j < MSS_LCAP ? sR[j] : ovf[j - MSS_LCAP].R; };
-    auto getSt = [&](int64_t j) -> int32_t { return j < MSS_LCAP ? sSt[j] : ovf[j - MSS_LCAP].st; };
-    auto getEn = [&](int64_t j) -> int32_t { return j < MSS_LCAP ? sEn[j] : ovf[j - MSS_LCAP].en; };
-    auto getPre = [&](int64_t j) -> int32_t { return j < MSS_LCAP ? sPre[j] : ovf[j - MSS_LCAP].pre; };
+    struct cand_v { double L, R; int32_t st, en, pre; };
+    auto get = [&](int64_t j) -> cand_v {
+        cand_v c;
+        if (j < MSS_LCAP) {
+            const double2 lr = sLR[j];
+            const int4 ix = sIdx[j];
+            c.L = lr.x; c.R = lr.y; c.st = ix.x; c.en = ix.y; c.pre = ix.z;
+        } else {
+            volatile mss_cand *o = ovf + (j - MSS_LCAP);
+            c.L = o->L; c.R = o->R; c.st = o->st; c.en = o->en; c.pre = o->pre;
+        }
+        return c;
+    };
 
     // mss.c:35-47, lane-parallel over the stack
     auto flush = [&]() {
@@ -502,10 +518,10 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
             bool keep = false;
             int32_t a = 0, b = 0;
             if (j < nst) {
-                const double sc = getR(j) - getL(j);
-                keep = sc >= min_sc;
-                a = getSt(j);
-                b = getEn(j);
+                const cand_v c = get(j);
+                keep = c.R - c.L >= min_sc;
+                a = c.st;
+                b = c.en;
             }
             const unsigned long long m = __ballot(keep);
             if (keep) {
@@ -526,14 +542,15 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
         int64_t j;
         for (;;) {
             j = nst - 1;
+            cand_v c;
             while (j >= 0) {
-                if (getL(j) < tL) break;
-                const int32_t pre = getPre(j);
-                j = pre >= 0 ? pre : j - 1;
+                c = get(j);
+                if (c.L < tL) break;
+                j = c.pre >= 0 ? c.pre : j - 1;
             }
-            if (j >= 0 && getR(j) < R) {
-                tst = getSt(j);
-                tL = getL(j);
+            if (j >= 0 && c.R < R) {
+                tst = c.st;
+                tL = c.L;
                 nst = j;
                 continue;
             }
@@ -541,7 +558,10 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
         }
         if (j < 0) { flush(); peak = R; }
         if (nst < MSS_LCAP) {
-            if (lane == 0) { sL[nst] = tL; sR[nst] = R; sSt[nst] = tst; sEn[nst] = (int32_t)en; sPre[nst] = (int32_t)j; }
+            if (lane == 0) {
+                sLR[nst] = make_double2(tL, R);
+                sIdx[nst] = make_int4(tst, (int32_t)en, (int32_t)j, 0);
+            }
         } else {
             // every lane stores the same record, so each lane later reads what it wrote itself
             volatile mss_cand *c = ovf + (nst - MSS_LCAP);
@@ -614,8 +634,8 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                 if ((mpos >> p) & 1ull) {
                     const unsigned long long z = ~mpos & rest;                     // first non-positive at or after p
                     const int e = z ? __builtin_ctzll(z) : nvalid;
-                    if (!run_open) { run_open = true; run_st = pos + p; run_L = p == 0 ? base : base + __shfl(pre, p - 1); }
-                    cur = base + __shfl(pre, e - 1);
+                    if (!run_open) { run_open = true; run_st = pos + p; run_L = p == 0 ? base : base + lane_value(pre, p - 1); }
+                    cur = base + lane_value(pre, e - 1);
                     p = e;
                     if (e < nvalid) close_run(cur, pos + e);
                 } else {
@@ -629,17 +649,17 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                             const int t = __builtin_ctzll(mt);
                             flush();
                             peak = MSS_NEG;
-                            base = t == 0 ? 0.0 : -__shfl(pre, t - 1);          // L = 0 before S[t] is added
+                            base = t == 0 ? 0.0 : -lane_value(pre, t - 1);          // L = 0 before S[t] is added
                         }
                     }
-                    cur = base + __shfl(pre, e - 1);
+                    cur = base + lane_value(pre, e - 1);
                     p = e;
                 }
             }
         } else {
             // ---- certificate failed: the reference loop, element by element ------------------
             for (int i = 0; i < nvalid; ++i) {
-                const double v = __shfl(s, i);
+                const double v = lane_value(s, i);
                 if (v > 0) {
                     if (!run_open) { run_open = true; run_st = pos + i; run_L = cur; }
                     cur = cur + v;

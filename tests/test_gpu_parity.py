@@ -277,6 +277,30 @@ def test_mss_stretch_parallel_vs_oracle(L, dev, orc, n, style):
     np.testing.assert_array_equal(lab_g, lab_o)
 
 
+@pytest.mark.parametrize("depth,xd", [(40, -1), (700, -1), (700, 50), (3000, 0)])
+def test_mss_deep_candidate_stack(L, dev, orc, depth, xd):
+    """Nested candidates (run starts rising, run ends falling) are neither merged nor flushed: the
+    candidate stack grows to `depth` entries, past the LDS-resident part into its HBM overflow."""
+    parts = []
+    for k in range(depth):
+        up, down = 2 * depth - 2 * k, 2 * depth - 2 * k - 1
+        parts += [np.full(3, up / 3.0 + 0.25), np.full(2, -(down / 2.0) - 0.125)]
+    tail = np.random.default_rng(depth).normal(0.2, 2.0, size=5000)
+    scores = np.concatenate(parts + [tail]).astype(np.float64)
+    n = scores.size
+    cls = (np.arange(n) % 4).astype(np.int64)
+    want, segs = orc.find_mss_labels(scores, cls, 4, 1, xd, return_segments=True)
+    d_s, d_l = _t(scores, dev), _t(cls.astype(np.int8), dev)
+    lab = torch.empty(n, dtype=torch.int8, device=dev)
+    wb = L.dgrp_mss_workspace_bytes(n)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    nseg = torch.zeros(1, dtype=torch.int64, device=dev)
+    _check(L.dgrp_mss_labels(d_s.data_ptr(), d_l.data_ptr(), n, 4, 1, xd, lab.data_ptr(), nseg.data_ptr(),
+                             work.data_ptr(), wb, _sp()))
+    assert int(nseg.item()) == len(segs)
+    np.testing.assert_array_equal(lab.cpu().numpy(), want)
+
+
 def test_softmax_path_golden(L, dev):
     g = golden("softmax.npz")
     probs = g["probs"]
