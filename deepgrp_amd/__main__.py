@@ -141,6 +141,7 @@ class CommandLineParser:
         import torch.distributed as dist
         from . import model as dgmodel
         from .distributed import gather_records, shard_contigs
+        from .fasta import DeviceRecord, read_multi_fasta_device
         from .pipeline import SEGMENT_DTYPE, ContigPipeline, upload_sequence
 
         world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,30 +166,38 @@ class CommandLineParser:
             return "".join("{}\t{}\t{}\t{}\t{}\n".format(filename, header, int(r["start"]), int(r["end"]), int(r["label"]))
                            for r in rows)
 
-        if world == 1:
-            for filename in args.FASTA:
-                _LOG.info("Processing %s", filename)
+        def run_record(rec, contig=0):
+            if isinstance(rec, DeviceRecord):                 # parsed and encoded on the GPU
+                if rec.length < 0:
+                    raise ValueError("negative dimensions are not allowed")     # all-N record, sequence.pyx:32
+                return pipe.run_idx(rec.d_idx, rec.startpos, contig)
+            return pipe.run(rec, contig)
+
+        def records_of(filename):
+            if filename == "-" or not os.path.isfile(filename):
                 filestream = sys.stdin if filename == "-" else open(filename, "r")
                 try:
-                    for header, dnasequence in _read_multi_fasta(filestream):
-                        rows = pipe.run(dnasequence)
-                        outstream.write(rows_text(filename, header, rows))
+                    yield from _read_multi_fasta(filestream)
                 finally:
                     if filename != "-":
                         filestream.close()
+            else:
+                yield from read_multi_fasta_device(filename)
+
+        if world == 1:
+            for filename in args.FASTA:
+                _LOG.info("Processing %s", filename)
+                for header, rec in records_of(filename):
+                    outstream.write(rows_text(filename, header, run_record(rec)))
         else:
             # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
             records = []
             for filename in args.FASTA:
-                filestream = sys.stdin if filename == "-" else open(filename, "r")
-                try:
-                    for header, dnasequence in _read_multi_fasta(filestream):
-                        records.append((filename, header, dnasequence))
-                finally:
-                    if filename != "-":
-                        filestream.close()
-            mine = shard_contigs([len(r[2]) for r in records], world)[rank]
-            parts = [pipe.run(records[i][2], contig=i) for i in mine]
+                for header, rec in records_of(filename):
+                    records.append((filename, header, rec))
+            length = lambda r: r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
+            mine = shard_contigs([length(r[2]) for r in records], world)[rank]
+            parts = [run_record(records[i][2], contig=i) for i in mine]
             local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
             allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
             if rank == 0:

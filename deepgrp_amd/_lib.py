@@ -26,6 +26,8 @@ _SIGNATURES = {
     "dgrp_strip_n": (cint, [vp, i64, C.POINTER(i64), C.POINTER(i64)]),
     "dgrp_encode": (cint, [vp, i64, vp, vp]),
     "dgrp_onehot": (cint, [vp, i64, vp, vp]),
+    "dgrp_fasta_workspace_bytes": (i64, [i64]),
+    "dgrp_fasta_encode": (cint, [vp, i64, vp, C.POINTER(i64), vp, i64, vp]),
     "dgrp_window_count": (i64, [i64, i64, i64]),
     "dgrp_windows_onehot": (cint, [vp, i64, i64, i64, i64, i64, cint, vp, vp]),
     "dgrp_model_create": (cint, [C.POINTER(vp), cint, cint, cint, cint, vp, vp, vp, vp, vp, vp]),

@@ -240,6 +240,131 @@ static int device_exclusive_scan(const uint64_t *in, uint64_t *out, int64_t n, u
 }
 
 // ------------------------------------------------------------------------------------------
+// A1 + A2 fused on the device: FASTA record body -> class indices (see include/deepgrp_hip.h).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fasta_class_of(uint32_t c)
+{
+    uint32_t l = c | 0x20u;
+    return l == 'a' ? 0u : l == 'c' ? 1u : l == 'g' ? 2u : l == 't' ? 3u : 4u;
+}
+
+// per tile: kept-byte count; globally: "not plain" flag.  g[0] = bad flag, g[1] = first non-N compact
+// index (atomicMin), g[2] = last non-N compact index + 1 (atomicMax)
+__global__ void __launch_bounds__(256) fasta_count_kernel(const uint8_t *__restrict__ raw, int64_t n, uint64_t *__restrict__ tilecnt,
+                                                          unsigned long long *__restrict__ g)
+{
+    __shared__ uint64_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    uint64_t c = 0;
+    bool bad = false;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) {
+            const uint32_t b = raw[i];
+            const bool lineend = b == '\n' || b == '\r';
+            c += lineend ? 0 : 1;
+            if (b >= 128 || (b <= 32 && !lineend)) bad = true;                      // non-ASCII / other whitespace
+            if (b == '\r' && (i + 1 >= n || raw[i + 1] != '\n')) bad = true;         // lone CR: a line break in text mode
+            if (b == '\n') {
+                if (i == 0) bad = true;                                             // body starts with a blank line
+                if (i + 1 < n && raw[i + 1] == '\n') bad = true;                     // blank line
+                if (i + 2 < n && raw[i + 1] == '\r' && raw[i + 2] == '\n') bad = true;
+            }
+            if (b == '\r' && i == 0) bad = true;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(&g[0], 1ull);
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ void __launch_bounds__(256) fasta_scatter_kernel(const uint8_t *__restrict__ raw, int64_t n,
+                                                            const uint64_t *__restrict__ tileoff, uint8_t *__restrict__ idx,
+                                                            unsigned long long *__restrict__ g)
+{
+    __shared__ uint64_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+    uint32_t b[8];
+    uint64_t s = 0;
+    for (int j = 0; j < 8; ++j) {
+        b[j] = base + j < n ? raw[base + j] : (uint32_t)'\n';
+        s += (b[j] == '\n' || b[j] == '\r') ? 0 : 1;
+    }
+    uint64_t ex = block_exclusive_scan(s, nullptr, lds) + tileoff[blockIdx.x];
+    long long first = 0x7fffffffffffffffll, last = -1;
+    for (int j = 0; j < 8; ++j) {
+        if (b[j] == '\n' || b[j] == '\r') continue;
+        idx[ex] = (uint8_t)fasta_class_of(b[j]);
+        if ((b[j] | 0x20u) != 'n') {                        // upper() precedes the N stripping in the reference
+            if ((long long)ex < first) first = (long long)ex;
+            last = (long long)ex + 1;
+        }
+        ++ex;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long f2 = __shfl_xor(first, o), l2 = __shfl_xor(last, o);
+        first = f2 < first ? f2 : first;
+        last = l2 > last ? l2 : last;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (last >= 0) {
+            atomicMin((unsigned long long *)&g[1], (unsigned long long)first);
+            atomicMax((unsigned long long *)&g[2], (unsigned long long)last);
+        }
+    }
+}
+
+DGRP_EXPORT int64_t dgrp_fasta_workspace_bytes(int64_t nbytes)
+{
+    if (nbytes < 0) return 0;
+    return dgrp_align_up(((nbytes + SCAN_TILE - 1) / SCAN_TILE + 2) * 8, 256) + 256;
+}
+
+DGRP_EXPORT int dgrp_fasta_encode(const uint8_t *d_raw, int64_t nbytes, uint8_t *d_idx, int64_t *h_info, void *d_work,
+                                  int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(nbytes >= 0 && h_info, "dgrp_fasta_encode: bad arguments");
+    h_info[0] = 1; h_info[1] = 0; h_info[2] = 0; h_info[3] = 0;
+    if (nbytes == 0) return DGRP_OK;
+    DGRP_REQUIRE(d_raw && d_idx && d_work, "dgrp_fasta_encode: NULL pointer");
+    if (work_bytes < dgrp_fasta_workspace_bytes(nbytes)) {
+        dgrp_set_error("dgrp_fasta_encode: workspace too small");
+        return DGRP_ENOMEM;
+    }
+    const int64_t ntiles = (nbytes + SCAN_TILE - 1) / SCAN_TILE;
+    uint64_t *tiles = (uint64_t *)d_work;
+    uint64_t *grand = tiles + ntiles + 1;                      // [0] scan total
+    unsigned long long *g = (unsigned long long *)((char *)d_work + dgrp_fasta_workspace_bytes(nbytes) - 256);
+    const unsigned long long init[3] = { 0ull, 0x7fffffffffffffffull, 0ull };
+    DGRP_HIP(hipMemcpyAsync(g, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(fasta_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_raw, nbytes, tiles, g);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, tiles, ntiles, grand);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fasta_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_raw, nbytes, tiles, d_idx, g);
+    DGRP_LAUNCH_CHECK();
+    unsigned long long hg[3];
+    uint64_t total = 0;
+    DGRP_HIP(hipMemcpyAsync(hg, g, sizeof(hg), hipMemcpyDeviceToHost, stream));
+    DGRP_HIP(hipMemcpyAsync(&total, grand, 8, hipMemcpyDeviceToHost, stream));
+    DGRP_HIP(hipStreamSynchronize(stream));
+    h_info[0] = hg[0] ? 0 : 1;
+    h_info[1] = (int64_t)total;
+    if (hg[2] == 0) {                                          // no non-N character at all
+        // sequence.pyx:27-30: startpos runs to the end, length runs to 0 -> negative unless empty
+        h_info[2] = (int64_t)total;
+        h_info[3] = -(int64_t)total;
+    } else {
+        h_info[2] = (int64_t)hg[1];
+        h_info[3] = (int64_t)hg[2] - (int64_t)hg[1];
+    }
+    return DGRP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // A10  mss_find_all (deepgrp/_mss/mss.c:50-101) -- "stretch-parallel, fixed-point, wave-chunked" form.
 //
 // The algorithm is a left fold in double precision (L += S[i]); re-associating it changes

@@ -1,0 +1,186 @@
+"""Fast (multi-)FASTA ingest with the exact semantics of the reference's line loop
+(deepgrp/__main__.py:20-43): every line is stripped, '>' lines open a record whose header is the
+rest of the line, other lines are upper-cased and concatenated, a record without header is
+dropped and a blank line raises IndexError.
+
+The reference loop costs ~1 us per line in Python (seconds for a chromosome); here a record whose
+body is plain ("ACGT...\\n" lines, optional CRLF, no other whitespace, ASCII) is assembled with
+bytes.translate/upper at memory speed and anything else falls back to the reference loop for that
+record, so results -- including where an exception is raised -- are identical.
+"""
+from __future__ import annotations
+
+import io
+import mmap
+import os
+from typing import Iterator, List, TextIO, Tuple, Union
+
+_DELETE = b"\n\r"
+_ODD_WHITESPACE = (b" ", b"\t", b"\x0b", b"\x0c", b"\x1c", b"\x1d", b"\x1e", b"\x1f", b"\x85")
+
+
+def read_multi_fasta_lines(filestream: TextIO) -> Iterator[Tuple[str, str]]:
+    """The reference loop, line by line (used for stdin and as the fallback)."""
+    header = ""
+    sequence: List[str] = []
+    for line in filestream:
+        line = line.strip()
+        if line[0] == ">":
+            if header:
+                yield header, "".join(sequence)
+            header = line[1:]
+            sequence = []
+        else:
+            sequence.append(line.upper())
+    if header:
+        yield header, "".join(sequence)
+
+
+_UPPER = bytes.maketrans(bytes(range(ord("a"), ord("z") + 1)), bytes(range(ord("A"), ord("Z") + 1)))
+
+
+def _plain(body) -> bool:
+    """True when stripping every line is the same as deleting CR/LF: ASCII, no whitespace or control
+    byte other than line ends, CR only as part of CRLF, no blank line."""
+    import numpy as np
+    arr = np.frombuffer(body, dtype=np.uint8)
+    if arr.size == 0:
+        return True
+    if int(arr.max()) >= 128:
+        return False
+    n_ctl = int(np.count_nonzero(arr <= 32))
+    n_lf, n_cr, n_crlf = body.count(b"\n"), body.count(b"\r"), body.count(b"\r\n")
+    if n_cr != n_crlf or n_ctl != n_lf + n_cr:
+        return False                                   # lone CR (a line break in text mode) or other whitespace
+    if b"\n\n" in body or b"\n\r\n" in body or body[:1] == b"\n" or body[:2] == b"\r\n":
+        return False                                   # blank line: let the reference loop raise
+    return True
+
+
+def read_multi_fasta_file(path: Union[str, os.PathLike]) -> Iterator[Tuple[str, Union[str, bytes]]]:
+    """Records of a FASTA file as (header, sequence); the sequence comes back as ASCII bytes on
+    the fast path (accepted by the device pipeline as is) or as str from the fallback."""
+    size = os.path.getsize(path)
+    if size == 0:
+        return
+    with open(path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+        # chunk boundaries: every "\n>" (a header at the start of a line) and the file start
+        starts = [0]
+        pos = mm.find(b"\n>")
+        while pos != -1:
+            starts.append(pos + 1)
+            pos = mm.find(b"\n>", pos + 1)
+        starts.append(size)
+        pending: List[Tuple[str, Union[str, bytes]]] = []
+        carry_header = ""            # state of the reference loop across chunks
+        carry_seq: List[str] = []
+        for a, b in zip(starts[:-1], starts[1:]):
+            chunk = mm[a:b]
+            nl = chunk.find(b"\n")
+            head, body = (chunk, b"") if nl == -1 else (chunk[:nl], chunk[nl + 1:])
+            if chunk.startswith(b">") and head.isascii() and _plain(body):
+                # flush whatever the fallback loop still holds, then emit this record directly
+                if carry_header:
+                    yield carry_header, "".join(carry_seq)
+                carry_header, carry_seq = "", []
+                header = head.decode("ascii").strip()[1:]
+                seq = body.translate(_UPPER, _DELETE)          # strip line ends + upper() in one pass
+                if header:
+                    # the reference yields a record when the NEXT header (or EOF) arrives; order is the same
+                    yield header, seq
+                continue
+            # fallback: run the reference loop over this chunk, continuing its state
+            text = io.TextIOWrapper(io.BytesIO(chunk), encoding=None, newline=None)
+            for line in text:
+                line = line.strip()
+                if line[0] == ">":
+                    if carry_header:
+                        yield carry_header, "".join(carry_seq)
+                    carry_header = line[1:]
+                    carry_seq = []
+                else:
+                    carry_seq.append(line.upper())
+        if carry_header:
+            yield carry_header, "".join(carry_seq)
+
+
+class DeviceRecord:
+    """A record whose sequence never existed as a Python string: class indices in HBM.
+    `d_idx` is the kept part (leading/trailing N dropped), `startpos` the number of leading N."""
+
+    __slots__ = ("startpos", "d_idx", "length")
+
+    def __init__(self, startpos, d_idx, length):
+        self.startpos, self.d_idx, self.length = startpos, d_idx, length
+
+
+def read_multi_fasta_device(path: Union[str, os.PathLike]):
+    """Like read_multi_fasta_file, but plain record bodies are uploaded as raw file bytes and turned
+    into class indices on the GPU (dgrp_fasta_encode: line-end removal, upper-casing, N stripping and
+    the class lookup of deepgrp/sequence.pyx in one pass).  Yields (header, DeviceRecord) for those
+    and (header, str) for records that need the reference loop."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from ._lib import check, lib
+    from .pipeline import require_gpu, stream_ptr
+
+    dev = require_gpu()
+    L = lib()
+    size = os.path.getsize(path)
+    if size == 0:
+        return
+    # ACCESS_COPY: a private, writable mapping (never written) so that torch accepts views of it
+    with open(path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_COPY) as mm:
+        starts = [0]
+        pos = mm.find(b"\n>")
+        while pos != -1:
+            starts.append(pos + 1)
+            pos = mm.find(b"\n>", pos + 1)
+        starts.append(size)
+        whole = np.frombuffer(mm, dtype=np.uint8)
+        carry_header = ""
+        carry_seq: List[str] = []
+        try:
+            for a, b in zip(starts[:-1], starts[1:]):
+                nl = mm.find(b"\n", a, b)
+                head_end = b if nl == -1 else nl
+                head = mm[a:head_end]
+                fast = mm[a:a + 1] == b">" and head.isascii()
+                if fast:
+                    body0 = b if nl == -1 else nl + 1
+                    nbytes = b - body0
+                    info = (C.c_int64 * 4)(1, 0, 0, 0)
+                    d_idx = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+                    if nbytes:
+                        d_raw = torch.from_numpy(whole[body0:b]).to(dev)        # numpy view of the mmap: no host copy
+                        wb = L.dgrp_fasta_workspace_bytes(nbytes)
+                        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+                        check(L.dgrp_fasta_encode(d_raw.data_ptr(), nbytes, d_idx.data_ptr(), info, work.data_ptr(), wb,
+                                                  stream_ptr()), "dgrp_fasta_encode")
+                    fast = info[0] == 1
+                if fast:
+                    if carry_header:
+                        yield carry_header, "".join(carry_seq)
+                    carry_header, carry_seq = "", []
+                    header = head.decode("ascii").strip()[1:]
+                    if header:
+                        st, kept = int(info[2]), int(info[3])
+                        yield header, DeviceRecord(st, d_idx[st:st + max(kept, 0)], kept)
+                    continue
+                text = io.TextIOWrapper(io.BytesIO(mm[a:b]), encoding=None, newline=None)
+                for line in text:
+                    line = line.strip()
+                    if line[0] == ">":
+                        if carry_header:
+                            yield carry_header, "".join(carry_seq)
+                        carry_header = line[1:]
+                        carry_seq = []
+                    else:
+                        carry_seq.append(line.upper())
+            if carry_header:
+                yield carry_header, "".join(carry_seq)
+        finally:
+            del whole                                   # release the buffer export before the mmap closes

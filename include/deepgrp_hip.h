@@ -65,6 +65,20 @@ int dgrp_encode(const uint8_t *d_seq, int64_t n, uint8_t *d_idx, void *stream);
 /* bytes -> int8 [5, n] C-order, exactly the array the reference function returns. */
 int dgrp_onehot(const uint8_t *d_seq, int64_t n, int8_t *d_onehot, void *stream);
 
+/* ---- A1+A2 fused for one record body: _read_multi_fasta's per-line strip()/upper()/join
+ * (deepgrp/__main__.py:31-41) followed by one_hot_encode_dna_sequence's N stripping and class lookup
+ * (deepgrp/sequence.pyx:27-35), on the raw bytes between a header line and the next header.
+ * d_raw [nbytes] device bytes as they are in the file; d_idx receives one class index per sequence
+ * character (line ends removed), BEFORE N stripping, capacity nbytes.  h_info (host, filled after a
+ * stream synchronisation): [0] 1 if the body is "plain" (ASCII, no whitespace except LF / CRLF line
+ * ends, no blank line) so that deleting line ends equals stripping every line -- otherwise the caller
+ * must parse this record with the reference loop; [1] sequence length; [2] startpos = number of leading
+ * 'N'/'n'; [3] kept length after dropping leading and trailing N (negative for an all-N record).
+ * The class indices of the kept part are d_idx[startpos .. startpos + kept). */
+int64_t dgrp_fasta_workspace_bytes(int64_t nbytes);
+int dgrp_fasta_encode(const uint8_t *d_raw, int64_t nbytes, uint8_t *d_idx, int64_t *h_info, void *d_work,
+                      int64_t work_bytes, void *stream);
+
 /* ---- A3: deepgrp.prediction.fetch_validation_batch (deepgrp/prediction.py:14-37)
  * Number of windows len(range(0, n - T, s)). */
 int64_t dgrp_window_count(int64_t n, int64_t T, int64_t s);

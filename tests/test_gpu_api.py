@@ -247,3 +247,57 @@ def test_trained_synthetic_model_calls_planted_repeats():
     truth = truth[st:st + labels.size]
     called = labels > 0
     assert (called[truth > 0]).mean() > 0.7 and (called[truth == 0]).mean() < 0.2
+
+
+def test_fasta_device_ingest_matches_reference_loop(orc, tmp_path):
+    """dgrp_fasta_encode + read_multi_fasta_device against the reference's line loop followed by the
+    oracle's one_hot_encode (strip N, class lookup): plain records (LF and CRLF, lower case, N flanks,
+    no final newline) take the device path, odd ones (inner whitespace, indented header, blank line)
+    fall back -- same records, same order, same exception."""
+    from deepgrp_amd.fasta import DeviceRecord, read_multi_fasta_device, read_multi_fasta_lines
+    rng = np.random.default_rng(4)
+
+    def seq(n, alphabet="ACGTNacgtnRYKM"):
+        return "".join(rng.choice(list(alphabet), size=n))
+
+    def wrap(s, w=60, nl="\n"):
+        return nl.join(s[i:i + w] for i in range(0, len(s), w))
+
+    files = {
+        "plain.fa": ">a desc\n" + wrap("NNNNnn" + seq(5000) + "NNn") + "\n>b\n" + wrap(seq(777), 70) + "\n>c\n" + wrap(seq(64)) ,
+        "crlf.fa": ">a\r\n" + wrap(seq(1000), 50, "\r\n") + "\r\n>b\r\nACGT\r\n",
+        "odd.fa": "junk\n>a\nAC GT\n  >b\nTT\n>c\n\tGG \n>d\n" + wrap(seq(300)) + "\n",
+        "alln.fa": ">x\nNNNN\nnnNN\n>y\nACGT\n",
+        "empty_header.fa": ">a\nACGT\n>\nGG\n>c\nTT\n>onlyheader\n",
+        "blank.fa": ">a\n" + wrap(seq(100)) + "\n\n>b\nAC\n",
+        "lonecr.fa": ">a\nAC\rGT\n",
+    }
+    for name, text in files.items():
+        path = tmp_path / name
+        path.write_bytes(text.encode())
+        want, werr = [], None
+        try:
+            with open(path, "r") as fh:
+                for h, s in read_multi_fasta_lines(fh):
+                    want.append((h, s))
+        except Exception as e:           # noqa: BLE001
+            werr = type(e).__name__
+        got, gerr, ndev = [], None, 0
+        try:
+            for h, rec in read_multi_fasta_device(str(path)):
+                if isinstance(rec, DeviceRecord):
+                    ndev += 1
+                    got.append((h, rec.startpos, rec.length, rec.d_idx.cpu().numpy()))
+                else:
+                    st, n = orc.strip_n(rec.encode())
+                    got.append((h, st, n, orc.encode_idx(rec.encode()[st:st + max(n, 0)])))
+        except Exception as e:           # noqa: BLE001
+            gerr = type(e).__name__
+        assert gerr == werr, name
+        assert len(got) == len(want), name
+        for (h, st, n, idx), (wh, ws) in zip(got, want):
+            wst, wn = orc.strip_n(ws.encode())
+            assert (h, st, n) == (wh, wst, wn), name
+            np.testing.assert_array_equal(idx, orc.encode_idx(ws.encode()[wst:wst + max(wn, 0)]))
+        if name in ("plain.fa", "crlf.fa", "alln.fa", "empty_header.fa"):
+            assert ndev >= 2, name
