@@ -754,6 +754,46 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
             }
             double base = cur;
             int p = 0;
+            // ---- (3c) growing-candidate shortcut.  With exactly one candidate c on the stack, a run whose
+            // start lies above c.L and whose end exceeds c.R is absorbed by c (mss.c:68-81: found, merged,
+            // stack empty, "flush", pushed again with R = the run's end, max = R).  If every run of the chunk
+            // does that -- run ends strictly increasing and above c.R, starts above c.L, no x-drop trigger,
+            // no run crossing the chunk edges -- the chunk only moves c.R / c.en / max: no serial stack work.
+            if (nst == 1 && !run_open && mpos != 0ull && !((mpos >> (nvalid - 1)) & 1ull)) {
+                const cand_v c0 = get(0);
+                const double V = base + pre;
+                const bool isend = ispos && !((mpos >> (lane + 1)) & 1ull) ;
+                const bool isstart = ispos && (lane == 0 || !((mpos >> (lane - 1)) & 1ull));
+                double vprev = __shfl_up(V, 1);
+                if (lane == 0) vprev = cur;
+                double rmax = isend ? V : -INFINITY;              // inclusive running max of run-end values
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const double y = __shfl_up(rmax, o);
+                    if (lane >= o) rmax = y > rmax ? y : rmax;
+                }
+                double before = __shfl_up(rmax, 1);               // run ends strictly before this lane
+                if (lane == 0) before = -INFINITY;
+                const double top_r = before > c0.R ? before : c0.R;
+                const double peak_i = before > -INFINITY ? before : peak;
+                bool ok = true;
+                if (isend) ok = V > top_r;                                        // seg.a[j].R < t.R
+                if (isstart) ok = ok && (c0.L < vprev);                          // p->L < t.L
+                if (lane < nvalid && !ispos && xdrop > 0.0 && V + xdrop < peak_i) ok = false;   // x-drop would fire
+                if (__all(ok)) {
+                    const int last = 63 - __builtin_clzll(mpos);                 // last positive lane = end of the last run
+                    const double newR = lane_value(V, last);
+                    if (lane == 0) {
+                        sLR[0] = make_double2(c0.L, newR);
+                        sIdx[0] = make_int4(c0.st, (int32_t)(pos + last + 1), -1, 0);
+                    }
+                    __threadfence_block();
+                    peak = newR;
+                    cur = lane_value(V, nvalid - 1);
+                    pos += nvalid;
+                    continue;
+                }
+            }
             while (p < nvalid) {
                 const unsigned long long rest = vmask & ~((1ull << p) - 1ull);     // lanes >= p
                 if ((mpos >> p) & 1ull) {

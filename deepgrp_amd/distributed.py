@@ -30,8 +30,8 @@ def gather_records(local: np.ndarray, device: torch.device) -> np.ndarray:
     """Concatenate every rank's SEGMENT_DTYPE records on rank 0 (other ranks get an empty
     array), ordered by (contig tag, start): all_gather of the counts, then one padded
     all_gather of the raw bytes -- kilobytes to a few MB, latency-bound on any fabric."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return np.sort(local, order=["contig", "start"])
+    if not dist.is_initialized():
+        return local                                    # single process: rows are already in record order
     world, rank = dist.get_world_size(), dist.get_rank()
     if dist.get_backend() == "gloo":
         device = torch.device("cpu")               # gloo has no GPU all_gather; RCCL ("nccl") takes HBM tensors

@@ -1,0 +1,47 @@
+"""The RCCL ("nccl") code path of the record gather on a real GPU.  Only one GPU is available to the
+tests, so the process group has a single rank: it still runs init_process_group("nccl"), barrier and
+the all_gather calls on HBM tensors exactly as the N > 1 launch does (the N = 2 logic itself is covered
+on CPU with gloo in tests/test_host.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _worker(q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    from deepgrp_amd.distributed import gather_records
+    from deepgrp_amd.pipeline import SEGMENT_DTYPE
+    rows = np.zeros(5, SEGMENT_DTYPE)
+    rows["start"] = [50, 10, 30, 5, 7]
+    rows["end"] = rows["start"] + 3
+    rows["label"] = [1, 2, 3, 4, 1]
+    rows["contig"] = [1, 1, 0, 0, 2]
+    out = gather_records(rows, dev)
+    empty = gather_records(np.zeros(0, SEGMENT_DTYPE), dev)
+    t = torch.ones(1, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    q.put((out.tolist(), len(empty), float(t.item())))
+    dist.destroy_process_group()
+
+
+def test_gather_records_over_rccl_single_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(q,))
+    p.start()
+    out, nempty, one = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert [r[3] for r in out] == [0, 0, 1, 1, 2] and [r[0] for r in out] == [5, 30, 10, 50, 7]
+    assert nempty == 0 and one == 1.0

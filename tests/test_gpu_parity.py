@@ -301,6 +301,33 @@ def test_mss_deep_candidate_stack(L, dev, orc, depth, xd):
     np.testing.assert_array_equal(lab.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("drift", [0.4, 0.05, -0.05, -0.4])
+@pytest.mark.parametrize("xd", [50, 2, -1])
+def test_mss_raw_scores_with_drift(L, dev, orc, drift, xd):
+    """Raw score arrays with upward / downward drift (one ever-growing candidate, or a new bottom at
+    every run) -- the chunk shortcuts of the scan must agree with the sequential oracle."""
+    rng = np.random.default_rng(int(abs(drift) * 100) + xd + 7)
+    n = 200_003
+    scores = np.round(rng.normal(drift, 1.0, size=n) * 1024) / 1024      # multiples of 2^-10: certified chunks
+    scores[rng.random(n) < 0.01] = 0.0
+    scores[50_000:50_300] = -40.0                                         # a forced reset somewhere
+    cls = rng.integers(0, 5, size=n).astype(np.int64)
+    want, segs = orc.find_mss_labels(scores, cls, 5, 3, xd, return_segments=True)
+    d_s, d_l = _t(scores, dev), _t(cls.astype(np.int8), dev)
+    lab = torch.empty(n, dtype=torch.int8, device=dev)
+    wb = L.dgrp_mss_workspace_bytes(n)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    nseg = torch.zeros(1, dtype=torch.int64, device=dev)
+    _check(L.dgrp_mss_labels(d_s.data_ptr(), d_l.data_ptr(), n, 5, 3, xd, lab.data_ptr(), nseg.data_ptr(),
+                             work.data_ptr(), wb, _sp()))
+    assert int(nseg.item()) == len(segs)
+    np.testing.assert_array_equal(lab.cpu().numpy(), want)
+    buf = np.zeros((max(len(segs), 1), 2), np.int32)
+    cnt = C.c_int64()
+    _check(L.dgrp_mss_segments_host(work.data_ptr(), work.numel(), buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
+    np.testing.assert_array_equal(buf[:len(segs)], np.array([(a, b) for a, b, _ in segs], np.int32).reshape(-1, 2))
+
+
 def test_softmax_path_golden(L, dev):
     g = golden("softmax.npz")
     probs = g["probs"]
