@@ -31,6 +31,7 @@ _SIGNATURES = {
     "dgrp_window_count": (i64, [i64, i64, i64]),
     "dgrp_windows_onehot": (cint, [vp, i64, i64, i64, i64, i64, cint, vp, vp]),
     "dgrp_model_create": (cint, [C.POINTER(vp), cint, cint, cint, cint, vp, vp, vp, vp, vp, vp]),
+    "dgrp_model_create_lstm": (cint, [C.POINTER(vp), cint, cint, cint, vp, vp, vp, vp, vp]),
     "dgrp_model_destroy": (cint, [vp]),
     "dgrp_model_dims": (cint, [vp, C.POINTER(cint), C.POINTER(cint), C.POINTER(cint), C.POINTER(cint)]),
     "dgrp_forward_workspace_bytes": (i64, [vp, i64]),

@@ -84,6 +84,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
 
     dgrp_model *m = new dgrp_model();
     m->T = T; m->u = u; m->C = C; m->attention = attention ? 1 : 0;
+    m->cell = 0;
     m->UP = (u + 31) / 32 * 32;
     m->NW = m->UP / 32;
     m->KS = m->UP / 16;
@@ -171,6 +172,74 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
         CREATE_HIP(hipMemcpy(m->d_wtop, wtop.data(), wtop.size() * 4, hipMemcpyHostToDevice));
     }
 #undef CREATE_HIP
+    *out = m;
+    return DGRP_OK;
+}
+
+DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, const float *kernel, const float *rec,
+                                       const float *bias, const float *ffk, const float *ffb)
+{
+    DGRP_REQUIRE(out, "dgrp_model_create_lstm: NULL out");
+    *out = nullptr;
+    DGRP_REQUIRE(T >= 1 && T <= 65535, "dgrp_model_create_lstm: window size %d out of range", T);
+    DGRP_REQUIRE(u >= 1 && u <= 128, "dgrp_model_create_lstm: units=%d not supported (1..128)", u);
+    DGRP_REQUIRE(C >= 2 && C <= 16, "dgrp_model_create_lstm: classes=%d not supported (2..16)", C);
+    DGRP_REQUIRE(kernel && rec && bias && ffk && ffb, "dgrp_model_create_lstm: NULL tensor");
+    char nm[8];
+    int rc = dgrp_device_info(nm, sizeof(nm), nullptr, nullptr);
+    if (rc != DGRP_OK) return rc;
+    dgrp_model *m = new dgrp_model();
+    m->T = T; m->u = u; m->C = C; m->attention = 0; m->cell = 1;
+    m->UP = (u + 31) / 32 * 32;
+    m->NW = m->UP / 32;
+    m->KS = m->UP / 16;
+    m->nfrag = 4 * (m->KS + 1) + 2;
+    m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr;
+    const int KS = m->KS, NF = m->nfrag, u4 = 4 * u;
+    std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
+    auto at = [&](int w, int f, int l, int j) -> uint16_t & { return pack[(((size_t)w * NF + f) * 64 + l) * 8 + j]; };
+    for (int w = 0; w < m->NW; ++w)
+        for (int l = 0; l < 64; ++l) {
+            const int unit = 32 * w + (l & 31);
+            const bool uok = unit < u;
+            for (int g = 0; g < 4; ++g) {
+                const float gs = g == 2 ? 2.8853900817779268f : -1.4426950408889634f;     // c: tanh, i/f/o: sigmoid
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 16 * ks + 8 * (l >> 5) + j;
+                        at(w, g * (KS + 1) + ks, l, j) = (uok && k < u) ? f2h(gs * rec[(size_t)k * u4 + g * u + unit]) : 0;
+                    }
+                for (int j = 0; j < 8; ++j) {
+                    float v = 0.0f;
+                    if (uok) {
+                        if (j < 5) v = kernel[(size_t)j * u4 + g * u + unit];
+                        else if (j == 5) v = bias[g * u + unit];
+                    }
+                    v *= gs;
+                    const uint16_t hi = f2h(v);
+                    at(w, g * (KS + 1) + KS, l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
+                }
+            }
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * (l >> 4) + j, du = 32 * w + k, c = l & 15;
+                float v = 0.0f;
+                if (du < u && c < C) v = 0.5f * ffk[(size_t)du * C + c];
+                const uint16_t hi = f2h(v);
+                at(w, 4 * (KS + 1), l, j) = hi;
+                at(w, 4 * (KS + 1) + 1, l, j) = f2h(v - h2f(hi));
+            }
+        }
+    float ffb16[16] = { 0 };
+    for (int c = 0; c < C; ++c) ffb16[c] = ffb[c];
+    hipError_t e = hipMalloc((void **)&m->d_pack, pack.size() * 2);
+    if (e == hipSuccess) e = hipMemcpy(m->d_pack, pack.data(), pack.size() * 2, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&m->d_ffb, sizeof(ffb16));
+    if (e == hipSuccess) e = hipMemcpy(m->d_ffb, ffb16, sizeof(ffb16), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        dgrp_set_error("dgrp_model_create_lstm: %s", hipGetErrorString(e));
+        dgrp_model_destroy(m);
+        return DGRP_EHIP;
+    }
     *out = m;
     return DGRP_OK;
 }

@@ -270,6 +270,174 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 }
 
 // ------------------------------------------------------------------------------------------
+// rnn = "LSTM" (deepgrp/model.py:219-223): same decomposition as the GRU kernel -- a workgroup owns 16
+// windows (32 rows), wave w owns units [32w, 32w+32) of all FOUR gates (i|f|c|o), fp32 cell and hidden
+// state in registers.  Four gate slices do not fit 256 VGPRs beyond 64 units, so from NW = 3 on the f
+// and o fragments are re-read from L2 every step (the i and c fragments stay resident).
+// Fragment order per wave: gate g, k-step k -> g*(KS+1)+k (k = KS: input projection + bias, hi|lo),
+// then dense hi, dense lo.  Scales folded in: -log2 e for i, f, o; 2 log2 e for c.
+// ------------------------------------------------------------------------------------------
+template <int NW, int MODE>
+__global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params p)
+{
+    constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;
+    constexpr bool STREAM = NW > 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    _Float16 *hbuf = reinterpret_cast<_Float16 *>(smem);
+    float *dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP));
+    uint8_t *seqs = smem + gru_lds_hbuf(UP) + gru_lds_dpart(NW);
+    int64_t *row0s = reinterpret_cast<int64_t *>(seqs + gru_lds_seq(p.Tp));
+    int *rowoff = reinterpret_cast<int *>(row0s + DGRP_WG_WINDOWS);
+    unsigned *obuf = reinterpret_cast<unsigned *>(rowoff + DGRP_WG_WINDOWS);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, C = p.C;
+    const int64_t wg_w = p.w0 + (int64_t)blockIdx.x * DGRP_WG_WINDOWS;
+    const int nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - wg_w);
+
+    const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
+    half8 Bi[KS + 1], Bf[KS + 1], Bc[KS + 1], Bo[KS + 1], Bd_hi, Bd_lo;
+#pragma unroll
+    for (int k = 0; k <= KS; ++k) {
+        Bi[k] = __builtin_bit_cast(half8, mypack[(size_t)(0 * (KS + 1) + k) * 64]);
+        Bc[k] = __builtin_bit_cast(half8, mypack[(size_t)(2 * (KS + 1) + k) * 64]);
+        if (!STREAM || k == KS) {
+            Bf[k] = __builtin_bit_cast(half8, mypack[(size_t)(1 * (KS + 1) + k) * 64]);
+            Bo[k] = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + k) * 64]);
+        }
+    }
+    Bd_hi = __builtin_bit_cast(half8, mypack[(size_t)(4 * (KS + 1)) * 64]);
+    Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(4 * (KS + 1) + 1) * 64]);
+
+    for (int i = tid; i < DGRP_WG_WINDOWS * T; i += 64 * NW) {
+        const int wi = i / T, t = i - wi * T;
+        seqs[wi * p.Tp + t] = wi < nvalid ? p.idx[(wg_w + wi) * p.s + t] : (uint8_t)4;
+    }
+    for (int i = tid; i < 32 * HS; i += 64 * NW) hbuf[i] = (_Float16)0.0f;
+    int64_t lo = 0;
+    if (MODE == 0) {
+        int64_t a = dgrp_place_row(p.place, wg_w, p.s), b = dgrp_place_row(p.place, wg_w + nvalid - 1, p.s);
+        lo = a < b ? a : b;
+        for (int i = tid; i < p.ospan * C; i += 64 * NW) obuf[i] = 0u;
+    }
+    if (tid < DGRP_WG_WINDOWS) {
+        int64_t r0 = -1;
+        int off = -1;
+        if (tid < nvalid) {
+            r0 = MODE == 0 ? dgrp_place_row(p.place, wg_w + tid, p.s) : (wg_w + tid - p.w0) * (int64_t)T;
+            if (MODE == 0 && r0 >= lo && r0 - lo + T <= p.ospan) off = (int)(r0 - lo);
+        }
+        row0s[tid] = r0;
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+
+    const int r = lane & 31, wi_a = r & 15, dir = r >> 4, khalf = lane >> 5;
+    const uint8_t *myseq = seqs + wi_a * p.Tp;
+    float h[16], c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { h[i] = 0.0f; c[i] = 0.0f; }
+    _Float16 *hcur = hbuf, *hnxt = hbuf + 32 * HS;
+    const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const f32x4 zero4 = { 0, 0, 0, 0 };
+    const int cls = lane & 15;
+    const float fbias = cls < C ? p.ffb[cls] : 0.0f;
+
+    auto finish_step = [&](int t) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            if (reg % NW != wave) continue;
+            const float *dp = dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
+            float sum = dp[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sum += dp[w * 64];
+            const int wi = 4 * (lane >> 4) + reg;
+            const float lg = cls < C ? sum + fbias : -INFINITY;
+            const float m = row_allmax(lg);
+            const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg - m));
+            const float val = e * __builtin_amdgcn_rcpf(row_allsum(e));
+            if (cls < C && wi < nvalid) {
+                if (MODE == 0) {
+                    const int off = rowoff[wi];
+                    if (off >= 0) {
+                        atomicMax(&obuf[(off + t) * C + cls], __float_as_uint(val));
+                    } else {
+                        const int64_t row = row0s[wi] + t;
+                        if (row < p.n) atomicMax(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
+                    }
+                } else {
+                    p.out[(row0s[wi] + t) * C + cls] = val;
+                }
+            }
+        }
+    };
+
+    for (int t = 0; t < T; ++t) {
+        if (t > 0) finish_step(t - 1);
+        uint32_t b = myseq[dir ? T - 1 - t : t];
+        if (dir) b = b < 4 ? 3 - b : 4;
+        const uint32_t one = 0x3C00u << ((b & 1) * 16);
+        const uint32_t sel = b >> 1;
+        const uint4 xu = make_uint4(sel == 0 ? one : 0u, sel == 1 ? one : 0u, (sel == 2 ? one : 0u) | 0x3C000000u, 0u);
+        const half8 xa = __builtin_bit_cast(half8, xu);
+        f32x16 ai = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bi[KS], zero16, 0, 0, 0);
+        f32x16 af = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bf[KS], zero16, 0, 0, 0);
+        f32x16 ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bc[KS], zero16, 0, 0, 0);
+        f32x16 ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bo[KS], zero16, 0, 0, 0);
+        const _Float16 *arow = hcur + r * HS + 8 * khalf;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const half8 a = *reinterpret_cast<const half8 *>(arow + 16 * k);
+            const half8 bf = STREAM ? __builtin_bit_cast(half8, mypack[(size_t)(1 * (KS + 1) + k) * 64]) : Bf[k];
+            const half8 bo = STREAM ? __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + k) * 64]) : Bo[k];
+            ai = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bi[k], ai, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bc[k], ac, 0, 0, 0);
+            af = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bf, af, 0, 0, 0);
+            ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bo, ao, 0, 0, 0);
+        }
+        // c = f*c + i*tanh(z_c) ; h = o*tanh(c)     (accumulators are in the exp2 domain)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float ig = sigmoid_from_scaled(ai[i]), fg = sigmoid_from_scaled(af[i]);
+            c[i] = fg * c[i] + ig * tanh_from_scaled(ac[i]);
+            h[i] = sigmoid_from_scaled(ao[i]) * fast_tanh(c[i]);
+        }
+        _Float16 *wcol = hnxt + 32 * wave + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * khalf;
+            wcol[row * HS] = (_Float16)h[i];
+        }
+        {
+            const _Float16 *drow = hnxt + (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
+            const half8 a0 = *reinterpret_cast<const half8 *>(drow);
+            const half8 a1 = *reinterpret_cast<const half8 *>(drow + 16 * HS);
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
+            float *dw = dpart + ((size_t)(t & 1) * 4 * NW + wave) * 64 + lane;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) dw[reg * NW * 64] = d[reg];
+        }
+        __syncthreads();
+        _Float16 *tmp = hcur; hcur = hnxt; hnxt = tmp;
+    }
+    finish_step(T - 1);
+    if (MODE == 0 && p.ospan > 0) {
+        __syncthreads();
+        unsigned *gout = reinterpret_cast<unsigned *>(p.out) + lo * C;
+        const int64_t lim = (p.n - lo) * C;
+        for (int i = tid; i < p.ospan * C; i += 64 * NW) {
+            const unsigned v = obuf[i];
+            if (v != 0u && i < lim) atomicMax(gout + i, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // AdditiveAttention(use_scale=True) + Dense + Softmax for the attention model
 // (model.py:309-319, :325-329).  One workgroup per window over the avg[t] tile kept by mode 2.
 //   q = avg-of-final-states = avg[T-1];  e[t] = sum_k scale[k] tanh(q[k] + avg[t,k]);
@@ -382,6 +550,23 @@ static int launch_gru(const gru_params &p, int64_t groups, size_t lds, hipStream
     }
 }
 
+template <int NW>
+static int launch_lstm(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
+{
+    static bool configured = false;
+    if (!configured) {
+        DGRP_HIP(hipFuncSetAttribute((const void *)lstm_fused_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DGRP_HIP(hipFuncSetAttribute((const void *)lstm_fused_kernel<NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    if (p.mode == 0)
+        hipLaunchKernelGGL((lstm_fused_kernel<NW, 0>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+    else
+        hipLaunchKernelGGL((lstm_fused_kernel<NW, 1>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
 int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
                     int64_t w0, int64_t nw, int mode, float *d_out, float *d_avg, hipStream_t stream)
 {
@@ -403,6 +588,17 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
+    if (m->cell == 1) {
+        switch (m->NW) {
+        case 1: return launch_lstm<1>(p, groups, lds, stream);
+        case 2: return launch_lstm<2>(p, groups, lds, stream);
+        case 3: return launch_lstm<3>(p, groups, lds, stream);
+        case 4: return launch_lstm<4>(p, groups, lds, stream);
+        default:
+            dgrp_set_error("LSTM units=%d not supported (max 128)", m->u);
+            return DGRP_EINVAL;
+        }
+    }
     switch (m->NW) {
     case 1: return launch_gru<1>(p, groups, lds, stream);
     case 2: return launch_gru<2>(p, groups, lds, stream);

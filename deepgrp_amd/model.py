@@ -125,16 +125,16 @@ def read_keras_hdf5(path: str) -> Dict[str, Any]:
         by_class: Dict[str, List[dict]] = {}
         for layer in layers:
             by_class.setdefault(layer["class_name"].split(">")[-1], []).append(layer)
-        if "LSTM" in by_class:
-            raise ModelFormatError("LSTM models (rnn='LSTM') are not supported by the HIP path yet")
-        if len(by_class.get("GRU", [])) != 1 or "InputLayer" not in by_class or "Softmax" not in by_class:
-            raise ModelFormatError("layer graph is not the one deepgrp.model.create_model builds (one shared GRU)")
-        gru = by_class["GRU"][0]
+        rnn = "LSTM" if "LSTM" in by_class else "GRU"
+        if len(by_class.get(rnn, [])) != 1 or "InputLayer" not in by_class or "Softmax" not in by_class:
+            raise ModelFormatError("layer graph is not the one deepgrp.model.create_model builds (one shared RNN layer)")
+        gru = by_class[rnn][0]
         gcfg = gru["config"]
-        if not (gcfg.get("reset_after", True) and gcfg.get("activation", "tanh") == "tanh"
-                and gcfg.get("recurrent_activation", "sigmoid") == "sigmoid" and gcfg.get("use_bias", True)
-                and not gcfg.get("go_backwards", False)):
-            raise ModelFormatError("GRU layer must use Keras defaults (reset_after, tanh, sigmoid, bias)")
+        if not (gcfg.get("activation", "tanh") == "tanh" and gcfg.get("recurrent_activation", "sigmoid") == "sigmoid"
+                and gcfg.get("use_bias", True) and not gcfg.get("go_backwards", False)):
+            raise ModelFormatError(f"{rnn} layer must use Keras defaults (tanh, sigmoid, bias)")
+        if rnn == "GRU" and not gcfg.get("reset_after", True):
+            raise ModelFormatError("GRU layer must use reset_after=True")
         rc = by_class.get("ReverseComplement", [])
         if len(rc) != 1 or list(rc[0]["config"].get("complements", [])) != _get_dna_encoding():
             raise ModelFormatError("ReverseComplement layer with complements [3,2,1,0,4] expected")
@@ -170,7 +170,13 @@ def read_keras_hdf5(path: str) -> Dict[str, Any]:
         dw = layer_weights(dense[0]["name"])
         res: Dict[str, Any] = dict(kernel=gw["kernel:0"], recurrent_kernel=gw["recurrent_kernel:0"], bias=gw["bias:0"],
                                    ff_kernel=dw["kernel:0"], ff_bias=dw["bias:0"], scale=None, vecsize=vecsize, units=units,
-                                   classes=classes, attention=attention, config=config)
+                                   classes=classes, attention=attention, config=config, rnn=rnn)
+        if rnn == "LSTM":
+            if attention:
+                raise ModelFormatError("attention is only defined for the GRU model (deepgrp/model.py:308)")
+            if res["bias"].reshape(-1).shape != (4 * units,):
+                raise ModelFormatError(f"LSTM bias has shape {res['bias'].shape}; expected ({4 * units},)")
+            return res
         if attention:
             aw = layer_weights(att[0]["name"])
             if att[0]["config"].get("use_scale", True):
@@ -189,12 +195,12 @@ def load_model(path: str, custom_objects: Optional[dict] = None):
     from .pipeline import DeviceModel
     w = read_keras_hdf5(path)
     model = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"],
-                        vecsize=w["vecsize"])
+                        vecsize=w["vecsize"], rnn=w["rnn"])
     model.config = w["config"]
     return model
 
 
-def keras_config(vecsize: int, units: int, classes: int, attention: bool, dropout: float = 0.25) -> dict:
+def keras_config(vecsize: int, units: int, classes: int, attention: bool, dropout: float = 0.25, rnn: str = "GRU") -> dict:
     """The functional-model config ``create_model`` produces (layer list as in the reference's
     tests/test_model.json), reduced to the keys this package reads back."""
     layers: List[dict] = [
@@ -209,7 +215,17 @@ def keras_config(vecsize: int, units: int, classes: int, attention: bool, dropou
                     "activation": "tanh", "recurrent_activation": "sigmoid", "use_bias": True, "dropout": dropout,
                     "recurrent_dropout": 0.0, "implementation": 2, "reset_after": True}},
     ]
-    if attention:
+    if rnn == "LSTM":
+        layers[2] = {"class_name": "LSTM", "name": "BLSTM",
+                     "inbound_nodes": [[["input_1", 0, 0, {}]], [["reverse_complement", 0, 0, {}]]],
+                     "config": {"name": "BLSTM", "trainable": True, "dtype": "float32", "return_sequences": True, "return_state": False,
+                                "go_backwards": False, "stateful": False, "unroll": False, "time_major": False, "units": units,
+                                "activation": "tanh", "recurrent_activation": "sigmoid", "use_bias": True, "unit_forget_bias": True,
+                                "dropout": dropout, "recurrent_dropout": 0.0, "implementation": 2}}
+        layers.append({"class_name": "Average", "name": "average", "config": {"name": "average"},
+                       "inbound_nodes": [[["BLSTM", 0, 0, {}], ["BLSTM", 1, 0, {}]]]})
+        last = "average"
+    elif attention:
         layers += [
             {"class_name": "Average", "name": "average", "config": {"name": "average"}, "inbound_nodes": [[["BGRU", 0, 1, {}], ["BGRU", 1, 1, {}]]]},
             {"class_name": "Reshape", "name": "reshape", "config": {"name": "reshape", "target_shape": [1, units]}, "inbound_nodes": [[["average", 0, 0, {}]]]},
@@ -235,7 +251,8 @@ def keras_config(vecsize: int, units: int, classes: int, attention: bool, dropou
                                                   "output_layers": [["softmax", 0, 0]]}}
 
 
-def save_keras_hdf5(path: str, kernel, recurrent_kernel, bias, ff_kernel, ff_bias, scale=None, vecsize: int = 200) -> None:
+def save_keras_hdf5(path: str, kernel, recurrent_kernel, bias, ff_kernel, ff_bias, scale=None, vecsize: int = 200,
+                    rnn: str = "GRU") -> None:
     """Write a model file in the layout ``model.save`` of the reference uses (root attribute
     ``model_config``; ``model_weights/<layer>/<weight name>`` datasets with ``weight_names``
     attributes).  Used for synthetic models in tests and benchmarks."""
@@ -246,16 +263,17 @@ def save_keras_hdf5(path: str, kernel, recurrent_kernel, bias, ff_kernel, ff_bia
     w = hdf5.Writer()
     w.set_attr("/", "keras_version", b"2.5.0")
     w.set_attr("/", "backend", b"tensorflow")
-    w.set_attr("/", "model_config", json.dumps(keras_config(vecsize, units, classes, attention)).encode("utf-8"))
-    layer_names = ["input_1", "reverse_complement", "BGRU"] + (
+    w.set_attr("/", "model_config", json.dumps(keras_config(vecsize, units, classes, attention, rnn=rnn)).encode("utf-8"))
+    rl, cell = ("BLSTM", "lstm_cell") if rnn == "LSTM" else ("BGRU", "gru_cell")
+    layer_names = ["input_1", "reverse_complement", rl] + (
         ["average", "reshape", "average_1", "additive_attention", "flatten", "repeat_vector", "concatenate"] if attention else ["average"]
     ) + ["FF", "softmax"]
     w.create_group("model_weights")
     w.set_attr("model_weights", "layer_names", [n.encode() for n in layer_names])
     w.set_attr("model_weights", "backend", b"tensorflow")
     w.set_attr("model_weights", "keras_version", b"2.5.0")
-    tensors = {"BGRU": [("BGRU/gru_cell/kernel:0", kernel), ("BGRU/gru_cell/recurrent_kernel:0", recurrent_kernel),
-                        ("BGRU/gru_cell/bias:0", bias)],
+    tensors = {rl: [(f"{rl}/{cell}/kernel:0", kernel), (f"{rl}/{cell}/recurrent_kernel:0", recurrent_kernel),
+                    (f"{rl}/{cell}/bias:0", bias)],
                "FF": [("FF/kernel:0", ff_kernel), ("FF/bias:0", ff_bias)]}
     if attention:
         tensors["additive_attention"] = [("additive_attention/scale:0", np.asarray(scale, np.float32).reshape(-1))]

@@ -47,7 +47,8 @@ class DeviceModel:
     fragments in HBM by ``dgrp_model_create``.  Mirrors the two Keras attributes the
     reference reads: ``input_shape`` (__main__.py:270) and ``output_shape`` (:75)."""
 
-    def __init__(self, kernel, recurrent_kernel, bias, ff_kernel, ff_bias, scale=None, vecsize: int = 200):
+    def __init__(self, kernel, recurrent_kernel, bias, ff_kernel, ff_bias, scale=None, vecsize: int = 200,
+                 rnn: str = "GRU"):
         require_gpu()
         f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
         self.kernel, self.recurrent_kernel, self.bias = f32(kernel), f32(recurrent_kernel), f32(bias)
@@ -57,7 +58,23 @@ class DeviceModel:
         self.classes = int(self.ff_bias.shape[0])
         self.vecsize = int(vecsize)
         self.attention = self.scale is not None
+        self.rnn = rnn
         u, c = self.units, self.classes
+        h = C.c_void_p()
+        if rnn == "LSTM":
+            # deepgrp/model.py:219-223: Keras LSTM, gate columns i|f|c|o, one bias vector, never with attention
+            self.bias = self.bias.reshape(-1)
+            if self.kernel.shape != (5, 4 * u) or self.recurrent_kernel.shape != (u, 4 * u) or self.bias.shape != (4 * u,):
+                raise ValueError(f"LSTM tensors have unexpected shapes {self.kernel.shape} {self.recurrent_kernel.shape} {self.bias.shape}")
+            if self.attention or self.ff_kernel.shape != (u, c):
+                raise ValueError("the LSTM model has no attention and a [units, classes] FF kernel")
+            check(lib().dgrp_model_create_lstm(C.byref(h), self.vecsize, u, c, _np_ptr(self.kernel),
+                                               _np_ptr(self.recurrent_kernel), _np_ptr(self.bias), _np_ptr(self.ff_kernel),
+                                               _np_ptr(self.ff_bias)), "dgrp_model_create_lstm")
+            self.handle = h
+            return
+        if rnn != "GRU":
+            raise ValueError(f"unknown rnn {rnn!r}")
         if self.kernel.shape != (5, 3 * u) or self.recurrent_kernel.shape != (u, 3 * u) or self.bias.shape != (2, 3 * u):
             raise ValueError(f"GRU tensors have unexpected shapes {self.kernel.shape} {self.recurrent_kernel.shape} "
                              f"{self.bias.shape}; expected reset_after GRU with 5 inputs")
@@ -65,7 +82,6 @@ class DeviceModel:
             raise ValueError(f"FF kernel shape {self.ff_kernel.shape} does not match units={u}, attention={self.attention}")
         if self.attention and self.scale.shape != (u,):
             raise ValueError("attention scale must have `units` entries")
-        h = C.c_void_p()
         check(lib().dgrp_model_create(C.byref(h), self.vecsize, u, c, int(self.attention), _np_ptr(self.kernel),
                                       _np_ptr(self.recurrent_kernel), _np_ptr(self.bias),
                                       _np_ptr(self.scale) if self.attention else None, _np_ptr(self.ff_kernel),

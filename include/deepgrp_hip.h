@@ -96,6 +96,11 @@ int dgrp_windows_onehot(const uint8_t *d_idx, int64_t n, int64_t T, int64_t s, i
 int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *h_kernel,
                       const float *h_recurrent, const float *h_bias, const float *h_scale,
                       const float *h_ff_kernel, const float *h_ff_bias);
+/* rnn = "LSTM" variant (deepgrp/model.py:219-223, no attention): kernel [5,4u], recurrent [u,4u],
+ * bias [4u], gate columns i|f|c|o; ff_kernel [u, C], ff_bias [C].  u <= 128. */
+int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, const float *h_kernel,
+                           const float *h_recurrent, const float *h_bias, const float *h_ff_kernel,
+                           const float *h_ff_bias);
 int dgrp_model_destroy(dgrp_model *m);
 int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int *attention);
 

@@ -535,6 +535,81 @@ static const int ORC_COMP[5] = { 3, 2, 1, 0, 4 };
 ORC_NN_IMPL(orc_nn_forward_f32, float, expf, tanhf)
 ORC_NN_IMPL(orc_nn_forward_f64, double, exp, tanh)
 
+/* ------------------------------------------------------------------------- */
+/* A4 (rnn = "LSTM"): deepgrp/model.py:219-223, :321-323                      */
+/* ------------------------------------------------------------------------- */
+/*
+ * Keras LSTM(units, activation=tanh, recurrent_activation=sigmoid, use_bias=True) -- the defaults
+ * recorded for the BLSTM layer in the reference's tests/test_model.json -- with kernel [5,4u],
+ * recurrent_kernel [u,4u], bias [4u], gate columns i|f|c|o:
+ *     z = x.W + h_prev.U + b ;  i = sig(z_i)  f = sig(z_f)  o = sig(z_o)
+ *     c = f * c_prev + i * tanh(z_c) ;  h = o * tanh(c)
+ * No attention with this cell (model.py:308); same reverse-complement / Average / Dense / Softmax.
+ */
+#define ORC_LSTM_IMPL(NAME, real_t, EXP, TANH)                                                   \
+    static void NAME##_one(const uint8_t *base, int T, int u, int C, const real_t *Wx,           \
+                           const real_t *U, const real_t *b, const real_t *Wd, const real_t *bd, \
+                           real_t *work, real_t *probs)                                          \
+    {                                                                                            \
+        real_t *hf = work, *hr = work + u, *cf = work + 2 * u, *cr = work + 3 * u;               \
+        real_t *g = work + 4 * u, *avg = work + 8 * u;                                           \
+        for (int k = 0; k < u; ++k) hf[k] = hr[k] = cf[k] = cr[k] = 0;                           \
+        for (int t = 0; t < T; ++t) {                                                            \
+            for (int dir = 0; dir < 2; ++dir) {                                                  \
+                real_t *h = dir ? hr : hf, *c = dir ? cr : cf;                                   \
+                int bs = dir ? ORC_COMP[base[T - 1 - t]] : base[t];                              \
+                const real_t *xw = Wx + (size_t)bs * 4 * u;                                      \
+                for (int j = 0; j < 4 * u; ++j) g[j] = xw[j] + b[j];                             \
+                for (int k = 0; k < u; ++k) {                                                    \
+                    const real_t hk = h[k];                                                      \
+                    const real_t *Uk = U + (size_t)k * 4 * u;                                    \
+                    for (int j = 0; j < 4 * u; ++j) g[j] += hk * Uk[j];                          \
+                }                                                                                \
+                for (int k = 0; k < u; ++k) {                                                    \
+                    real_t ig = 1 / (1 + EXP(-g[k]));                                            \
+                    real_t fg = 1 / (1 + EXP(-g[u + k]));                                        \
+                    real_t og = 1 / (1 + EXP(-g[3 * u + k]));                                    \
+                    c[k] = fg * c[k] + ig * TANH(g[2 * u + k]);                                  \
+                    h[k] = og * TANH(c[k]);                                                      \
+                }                                                                                \
+            }                                                                                    \
+            for (int k = 0; k < u; ++k) avg[(size_t)t * u + k] = (hf[k] + hr[k]) / 2;            \
+        }                                                                                        \
+        for (int t = 0; t < T; ++t) {                                                            \
+            real_t lg[16], mx = -INFINITY, den = 0;                                              \
+            for (int c = 0; c < C; ++c) {                                                        \
+                real_t acc = bd[c];                                                              \
+                for (int k = 0; k < u; ++k) acc += avg[(size_t)t * u + k] * Wd[(size_t)k * C + c]; \
+                lg[c] = acc;                                                                     \
+                if (acc > mx) mx = acc;                                                          \
+            }                                                                                    \
+            for (int c = 0; c < C; ++c) { lg[c] = EXP(lg[c] - mx); den += lg[c]; }               \
+            for (int c = 0; c < C; ++c) probs[(size_t)t * C + c] = lg[c] / den;                  \
+        }                                                                                        \
+    }                                                                                            \
+    ORC_API int NAME(const uint8_t *idx, int64_t s, int64_t w0, int64_t nw, int T, int u, int C, \
+                     const real_t *Wx, const real_t *U, const real_t *bias, const real_t *Wd,    \
+                     const real_t *bd, real_t *probs, int threads)                               \
+    {                                                                                            \
+        if (C > 16) return -1;                                                                   \
+        size_t wsz = (size_t)8 * u + (size_t)T * u;                                              \
+        int nt = threads > 0 ? threads : 1;                                                      \
+        real_t *work = (real_t *)malloc(sizeof(real_t) * wsz * (size_t)nt);                      \
+        if (!work) return -2;                                                                    \
+        _Pragma("omp parallel for num_threads(nt) schedule(dynamic, 4)")                         \
+        for (int64_t w = 0; w < nw; ++w) {                                                       \
+            int tid = 0;                                                                         \
+            ORC_TID(tid);                                                                        \
+            NAME##_one(idx + (w0 + w) * s, T, u, C, Wx, U, bias, Wd, bd, work + wsz * (size_t)tid, \
+                       probs + (size_t)w * T * C);                                               \
+        }                                                                                        \
+        free(work);                                                                              \
+        return 0;                                                                                \
+    }
+
+ORC_LSTM_IMPL(orc_lstm_forward_f32, float, expf, tanhf)
+ORC_LSTM_IMPL(orc_lstm_forward_f64, double, exp, tanh)
+
 ORC_API int orc_max_threads(void)
 {
 #ifdef _OPENMP

@@ -73,6 +73,10 @@ def lib() -> C.CDLL:
         f.restype = C.c_int
         f.argtypes = [vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int,
                       vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    for name in ("orc_lstm_forward_f32", "orc_lstm_forward_f64"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
     L.orc_max_threads.restype = C.c_int
     _LIB = L
     return L
@@ -289,6 +293,51 @@ def nn_forward(idx: np.ndarray, wts: Weights, s: int, w0: int, nw: int,
            _p(k), _p(r), _p(b), _p(sc), _p(fk), _p(fb), _p(probs), threads)
     if rc != 0:
         raise RuntimeError(f"orc_nn_forward failed: {rc}")
+    return probs
+
+
+class LSTMWeights:
+    """Keras tensors of the rnn="LSTM" model (deepgrp/model.py:219-223): kernel [5,4u],
+    recurrent_kernel [u,4u], bias [4u] (gate columns i|f|c|o), ff_kernel [u,C], ff_bias [C]."""
+
+    def __init__(self, kernel, recurrent, bias, ff_kernel, ff_bias, T=200):
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        self.kernel, self.recurrent, self.bias = f32(kernel), f32(recurrent), f32(bias).reshape(-1)
+        self.ff_kernel, self.ff_bias = f32(ff_kernel), f32(ff_bias)
+        self.T = int(T)
+        self.u = self.recurrent.shape[0]
+        self.C = self.ff_bias.shape[0]
+        assert self.kernel.shape == (5, 4 * self.u) and self.recurrent.shape == (self.u, 4 * self.u)
+        assert self.bias.shape == (4 * self.u,) and self.ff_kernel.shape == (self.u, self.C)
+
+    @classmethod
+    def random(cls, u, C=5, T=200, seed=7, gain=1.0):
+        rng = np.random.default_rng(seed)
+
+        def glorot(shape):
+            lim = np.sqrt(6.0 / (shape[0] + shape[-1]))
+            return rng.uniform(-lim, lim, size=shape)
+
+        q, r = np.linalg.qr(rng.normal(size=(4 * u, u)))
+        bias = rng.normal(scale=0.05, size=4 * u)
+        bias[u:2 * u] += 1.0                                   # unit_forget_bias=True
+        return cls(glorot((5, 4 * u)) * gain, (q * np.sign(np.diag(r))).T * gain, bias, glorot((u, C)) * gain,
+                   rng.normal(scale=0.05, size=C), T)
+
+
+def lstm_forward(idx: np.ndarray, wts: "LSTMWeights", s: int, w0: int, nw: int, dtype=np.float64, threads: int = 0):
+    L = lib()
+    f = L.orc_lstm_forward_f64 if dtype == np.float64 else L.orc_lstm_forward_f32
+    cast = lambda a: np.ascontiguousarray(a, dtype)
+    probs = np.empty((nw, wts.T, wts.C), dtype)
+    idx = np.ascontiguousarray(idx, np.uint8)
+    assert nw == 0 or (w0 + nw - 1) * s + wts.T <= idx.size
+    k, r, b, fk, fb = map(cast, (wts.kernel, wts.recurrent, wts.bias, wts.ff_kernel, wts.ff_bias))
+    if threads <= 0:
+        threads = L.orc_max_threads()
+    rc = f(_p(idx), s, w0, nw, wts.T, wts.u, wts.C, _p(k), _p(r), _p(b), _p(fk), _p(fb), _p(probs), threads)
+    if rc != 0:
+        raise RuntimeError(f"orc_lstm_forward failed: {rc}")
     return probs
 
 

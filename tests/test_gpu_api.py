@@ -233,6 +233,30 @@ def test_cli_end_to_end(orc, tmp_path, argv_style, use_mss):
     assert want.count("\n") > 3
 
 
+def test_cli_with_lstm_model(orc, tmp_path):
+    """`deepgrp predict` with an rnn="LSTM" model file: rows equal the oracle's post-processing of the
+    GPU probabilities, probabilities within 1e-3 of the float64 LSTM statement."""
+    from deepgrp_amd.__main__ import main
+    from deepgrp_amd.pipeline import upload_sequence
+    w = orc.LSTMWeights.random(48, 5, 40, seed=9, gain=2.0)
+    mpath = str(tmp_path / "lstm.hdf5")
+    dgmodel.save_keras_hdf5(mpath, w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=40, rnn="LSTM")
+    rng = np.random.default_rng(2)
+    seq = "NN" + "".join(rng.choice(list("ACGT"), size=6000)) + "N"
+    fasta = tmp_path / "x.fa"
+    fasta.write_text(">r1\n" + seq + "\n")
+    out = tmp_path / "o.tsv"
+    main(["-s", "10", "-b", "9", "-l", "4", "-x", "6", "predict", mpath, str(fasta), "--output", str(out)])
+    model = dgmodel.load_model(mpath)
+    assert model.rnn == "LSTM"
+    st, d_idx = upload_sequence(seq.encode())
+    nwin = orc.window_count(d_idx.numel(), 40, 10)
+    probs = model.forward_windows(d_idx, 10, 0, nwin).cpu().numpy()
+    assert np.abs(probs - orc.lstm_forward(d_idx.cpu().numpy(), w, 10, 0, nwin, np.float64)).max() < 1e-3
+    rows = orc.predict_contig(seq, lambda _i: (lambda a, b: probs[a:a + b]), 40, 5, 10, 9, 4, 6, True)
+    assert out.read_text() == "".join(f"{fasta}\tr1\t{a}\t{b}\t{c}\n" for a, b, c in rows)
+
+
 def test_trained_synthetic_model_calls_planted_repeats():
     """The benchmark model (tools/train_synth_model.py) on a fresh synthetic chromosome: most
     planted repeat bases are called, most background is confident class 0."""

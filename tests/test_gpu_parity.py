@@ -144,6 +144,29 @@ def test_forward_windows_vs_oracle(dev, orc, u, T, attention, gain, s, nw):
     dm.close()
 
 
+@pytest.mark.parametrize("u,T,gain,s,nw", [(16, 30, 1.0, 4, 21), (64, 50, 1.5, 7, 40), (96, 40, 1.0, 9, 17),
+                                           (128, 200, 1.0, 50, 35), (128, 60, 2.0, 25, 33), (100, 25, 1.0, 3, 19)])
+def test_lstm_forward_vs_oracle(dev, orc, u, T, gain, s, nw):
+    """rnn="LSTM" (deepgrp/model.py:219-223) through the HIP kernel against the float64 statement."""
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel
+    rng = np.random.default_rng(u + T)
+    w = orc.LSTMWeights.random(u, 5, T, seed=u, gain=gain)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T, rnn="LSTM")
+    n = (nw + 2) * s + T
+    idx = _seq_idx(rng, n)
+    want = orc.lstm_forward(idx, w, s, 2, nw, np.float64)
+    got = dm.forward_windows(_t(idx, dev), s, 2, nw).cpu().numpy()
+    err = np.abs(got - want).max()
+    print(f"LSTM u={u} T={T} gain={gain}: max |dp| = {err:.2e}")
+    assert err < 1e-3
+    # fused merge == get_max of the same probabilities, incl. the short-batch placement
+    nwin = orc.window_count(n, T, s)
+    probs = dm.forward_windows(_t(idx, dev), s, 0, nwin).cpu().numpy()
+    merged = ContigPipeline(dm, s, 7).merged(_t(idx, dev)).cpu().numpy()
+    np.testing.assert_array_equal(merged, orc.merge_all(probs, n, s, 7))
+    dm.close()
+
+
 def test_predict_on_batch_keras_style(dev, orc):
     rng = np.random.default_rng(3)
     w, dm = _model(orc, 32, 24, False, 1.0)

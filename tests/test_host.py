@@ -118,12 +118,24 @@ def test_hdf5_writer_round_trip(tmp_path, attention):
         np.testing.assert_array_equal(r["scale"], w["scale"])
 
 
+def test_hdf5_lstm_round_trip(tmp_path, orc):
+    """rnn="LSTM" model files (BLSTM/lstm_cell/... tensors, class_name LSTM in model_config)."""
+    w = orc.LSTMWeights.random(24, 5, 30)
+    path = str(tmp_path / "lstm.hdf5")
+    dgmodel.save_keras_hdf5(path, w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=30, rnn="LSTM")
+    r = dgmodel.read_keras_hdf5(path)
+    assert (r["rnn"], r["units"], r["vecsize"], r["classes"], r["attention"]) == ("LSTM", 24, 30, 5, False)
+    for k, v in (("kernel", w.kernel), ("recurrent_kernel", w.recurrent), ("ff_kernel", w.ff_kernel), ("ff_bias", w.ff_bias)):
+        np.testing.assert_array_equal(r[k], v)
+    np.testing.assert_array_equal(r["bias"].reshape(-1), w.bias)
+
+
 def test_model_format_errors(tmp_path):
     w = hdf5.Writer()
     w.set_attr("/", "model_config", b'{"class_name": "Functional", "config": {"layers": [{"class_name": "LSTM", "name": "BLSTM", "config": {}}]}}')
     w.create_group("model_weights")
     w.save(str(tmp_path / "lstm.h5"))
-    with pytest.raises(dgmodel.ModelFormatError, match="LSTM"):
+    with pytest.raises(dgmodel.ModelFormatError, match="layer graph"):
         dgmodel.read_keras_hdf5(str(tmp_path / "lstm.h5"))
     w2 = hdf5.Writer()
     w2.create_dataset("x", np.arange(3, dtype=np.float32))

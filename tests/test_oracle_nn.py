@@ -69,3 +69,32 @@ def test_gru_vs_torch(orc, u, T):
     p = np.exp(logits - logits.max(axis=2, keepdims=True))
     p /= p.sum(axis=2, keepdims=True)
     np.testing.assert_allclose(ours, p, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("u,T", [(16, 30), (48, 25)])
+def test_lstm_vs_torch(orc, u, T):
+    """rnn="LSTM" (deepgrp/model.py:219-223): the C statement against torch.nn.LSTM (same gate order
+    i|f|g|o as Keras' i|f|c|o; torch carries two bias vectors, the second is zero here)."""
+    rng = np.random.default_rng(5)
+    w = orc.LSTMWeights.random(u, 5, T, seed=4, gain=1.3)
+    idx = _idx(rng, T + 40)
+    nw, s = 6, 8
+    ours = orc.lstm_forward(idx, w, s, 0, nw, np.float64)
+    ours32 = orc.lstm_forward(idx, w, s, 0, nw, np.float32)
+    np.testing.assert_allclose(ours32, ours, atol=2e-5)
+    lstm = torch.nn.LSTM(5, u, batch_first=True).double()
+    with torch.no_grad():
+        lstm.weight_ih_l0.copy_(torch.from_numpy(w.kernel.astype(np.float64).T.copy()))
+        lstm.weight_hh_l0.copy_(torch.from_numpy(w.recurrent.astype(np.float64).T.copy()))
+        lstm.bias_ih_l0.copy_(torch.from_numpy(w.bias.astype(np.float64)))
+        lstm.bias_hh_l0.zero_()
+    win = np.stack([idx[i * s:i * s + T] for i in range(nw)]).astype(np.int64)
+    comp = np.array([3, 2, 1, 0, 4])
+    with torch.no_grad():
+        f, _ = lstm(torch.from_numpy(np.eye(5)[win]))
+        r, _ = lstm(torch.from_numpy(np.eye(5)[comp[win[:, ::-1]]]))
+    avg = ((f + r) / 2).numpy()
+    logits = avg @ w.ff_kernel.astype(np.float64) + w.ff_bias.astype(np.float64)
+    p = np.exp(logits - logits.max(axis=2, keepdims=True))
+    p /= p.sum(axis=2, keepdims=True)
+    np.testing.assert_allclose(ours, p, rtol=0, atol=1e-12)
