@@ -77,9 +77,13 @@ __host__ __device__ static inline int gru_lds_dpart(int NW) { return 2 * NW * 64
 __host__ __device__ static inline int gru_lds_seq(int Tp) { return DGRP_WG_WINDOWS * Tp; }
 __host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 8 + DGRP_WG_WINDOWS * 4; }
 
+#ifndef DGRP_PIPE
+#define DGRP_PIPE 1
+#endif
 template <int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params p)
 {
+    constexpr bool PIPE = DGRP_PIPE;
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;   // HS: padded row pitch (halves) -> conflict-free b128 reads
     // u > 128: the three gate slices no longer fit 256 VGPRs; the z gate's fragments (needed last in a
     // step) are then re-read from L2 every step (16 KB per wave-step, a few % of L2 bandwidth)
@@ -200,21 +204,36 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         const uint4 xu = make_uint4(sel == 0 ? one : 0u, sel == 1 ? one : 0u, (sel == 2 ? one : 0u) | 0x3C000000u, 0u);
         const half8 xa = __builtin_bit_cast(half8, xu);
 
-        f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Br[KS], zero16, 0, 0, 0);
-        f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bg[KS], zero16, 0, 0, 0);
-        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bz[KS], zero16, 0, 0, 0);
+        // Software pipeline inside the wave (the matrix pipe and the VALU only overlap for instructions
+        // that are interleaved in program order): r chain | g chain + sigmoid(r) | z chain + r*g | input
+        // projection of the candidate.
         const _Float16 *arow = hcur + r * HS + 8 * khalf;
+        half8 af[KS];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) af[k] = *reinterpret_cast<const half8 *>(arow + 16 * k);
+        f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Br[KS], zero16, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], Br[k], ar, 0, 0, 0);
+        f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bg[KS], zero16, 0, 0, 0);
+        float rr[16];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            const half8 a = *reinterpret_cast<const half8 *>(arow + 16 * k);
-            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Br[k], ar, 0, 0, 0);
-            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, Bg[k], ag, 0, 0, 0);
-            const half8 bz = ZSTREAM ? __builtin_bit_cast(half8, mypack[(size_t)k * 64]) : Bz[k];
-            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bz, az, 0, 0, 0);
-        }
-        // ---- gates (Keras GRUCell, reset_after=True), accumulators are in the exp2 domain -----
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], Bg[k], ag, 0, 0, 0);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ag[i] *= sigmoid_from_scaled(ar[i]);     // r * (h.U_h + b_rec_h)
+            for (int i = k * 16 / KS; i < (k + 1) * 16 / KS; ++i) rr[i] = sigmoid_from_scaled(ar[i]);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bz[KS], zero16, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const half8 bz = ZSTREAM ? __builtin_bit_cast(half8, mypack[(size_t)k * 64]) : Bz[k];
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], bz, az, 0, 0, 0);
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = k * 16 / KS; i < (k + 1) * 16 / KS; ++i) ag[i] *= rr[i];          // r * (h.U_h + b_rec_h)
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
+        }
         ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bxh, ag, 0, 0, 0);    // + x.W_h + b_in_h
 #pragma unroll
         for (int i = 0; i < 16; ++i) az[i] = sigmoid_from_scaled(az[i]);
