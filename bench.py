@@ -42,6 +42,7 @@ def cpu_baseline(weights, sample_bp: int):
     w = orc.Weights(weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
                     weights["ff_bias"], weights["scale"], T)
     threads = orc.lib().orc_max_threads()
+    sample_bp = min(sample_bp, max(50_000, 25_000 * threads))     # ~10-30 s of wall clock whatever the core count
 
     def factory(idx):
         return lambda w0, nw: orc.nn_forward(idx, w, STEP, w0, nw, np.float32, threads)
@@ -151,7 +152,8 @@ def main():
             "metric": "Mbp/sec predicted (whole node) at window=200 stride=50, 5-class",
             "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 MFMA operands / f32 accumulate+state (GRU); f32/f64/int post-processing",
+            "vs_baseline": None, "dtype": "f16",
+            "dtype_detail": "GRU: f16 MFMA operands, f32 accumulate and state; post-processing f32/f64/int exactly as the reference",
             "data": "synthetic",
             "config": {"workload": f"{args.mbp:g} Mbp synthetic chromosome per GPU (BASELINE configs[1]), "
                                    f"window={T} stride={STEP} hidden={UNITS} {CLASSES}-class, batch_size={BATCH}, "

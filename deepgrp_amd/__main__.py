@@ -96,6 +96,9 @@ class CommandLineParser:
         predict.add_argument("FASTA", nargs="+", type=str, help="Fasta input files ('-' = stdin)")
         predict.add_argument("--output", type=str, default="-", help="Output filename")
         predict.add_argument("--no_use_mss", "-m", action="store_true", help="Disable maximum scoring segment algorithm")
+        predict.add_argument("--split_contigs", action="store_true",
+                             help="multi-GPU only: spread the windows of EVERY record over all GPUs (for a few huge "
+                                  "records) instead of sharding whole records")
 
     def parse_args(self, argv=None) -> "CommandLineParser":
         argv = list(sys.argv[1:] if argv is None else argv)
@@ -150,7 +153,7 @@ class CommandLineParser:
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         if world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl")
+            dist.init_process_group(os.environ.get("DGRP_DIST_BACKEND", "nccl"))
 
         _LOG.debug("Loading model %s!", args.model)
         model = dgmodel.load_model(args.model, custom_objects={"ReverseComplement": None})
@@ -196,10 +199,25 @@ class CommandLineParser:
                 for header, rec in records_of(filename):
                     records.append((filename, header, rec))
             length = lambda r: r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
-            mine = shard_contigs([length(r[2]) for r in records], world)[rank]
-            parts = [run_record(records[i][2], contig=i) for i in mine]
-            local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
-            allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
+            if getattr(args, "split_contigs", False):
+                from .distributed import merged_split
+                parts = []
+                for i, (_f, _h, rec) in enumerate(records):
+                    if isinstance(rec, DeviceRecord):
+                        if rec.length < 0:
+                            raise ValueError("negative dimensions are not allowed")
+                        startpos, d_idx = rec.startpos, rec.d_idx
+                    else:
+                        startpos, d_idx = upload_sequence(rec.encode("utf-8"))
+                    merged = merged_split(pipe, d_idx)
+                    if rank == 0:
+                        parts.append(pipe.segments(pipe.labels(merged), startpos, i))
+                allrows = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
+            else:
+                mine = shard_contigs([length(r[2]) for r in records], world)[rank]
+                parts = [run_record(records[i][2], contig=i) for i in mine]
+                local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
+                allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
             if rank == 0:
                 for i, (filename, header, _seq) in enumerate(records):
                     outstream.write(rows_text(filename, header, allrows[allrows["contig"] == i]))

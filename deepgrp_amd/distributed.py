@@ -61,3 +61,77 @@ def predict_records_sharded(records: Sequence[Tuple[str, str]], run_one: Callabl
     parts = [run_one(records[i][1], i) for i in mine]
     local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
     return gather_records(local, device)
+
+
+# ---------------------------------------------------------------------------------------------
+# One record across several GPUs (SURVEY 8e "if a single contig must be split", N1)
+# ---------------------------------------------------------------------------------------------
+def window_share(nwin: int, world: int, rank: int, align: int = 16):
+    """Contiguous window range [a, b) of `rank`: equal shares in units of `align` windows (the GRU
+    kernel's workgroup granularity)."""
+    units = (nwin + align - 1) // align
+    per, extra = divmod(units, world)
+    a = (rank * per + min(rank, extra)) * align
+    b = ((rank + 1) * per + min(rank + 1, extra)) * align
+    return min(a, nwin), min(b, nwin)
+
+
+def placement_rows(a: int, b: int, nwin: int, batch: int, step: int, T: int):
+    """Row range [lo, hi) the windows [a, b) are merged into, with the reference's partial-last-batch
+    offset (deepgrp/prediction.py:104-105)."""
+    if b <= a:
+        return 0, 0
+    nfull, r = divmod(nwin, batch)
+    first_short = nfull * batch
+
+    def row(w):
+        return w * step if w < first_short else (nfull * r + (w - first_short)) * step
+
+    ends = [a, b - 1]
+    if a < first_short < b:
+        ends += [first_short - 1, first_short]
+    rows = [row(w) for w in ends]
+    return min(rows), max(rows) + T
+
+
+def merged_split(pipe, d_idx: torch.Tensor) -> torch.Tensor:
+    """The max-merged probability array [N, C] of ONE record computed by all ranks together: every
+    rank runs the fused GRU kernel on its share of the windows into a buffer that covers just its rows,
+    rank 0 gathers the slices and max-combines them (neighbouring shares overlap by T - step rows; max
+    is exact, so the result is bit-identical to a single-GPU run).  Returned on rank 0 (None elsewhere).
+    The sequential post-processing (scores, MSS, segments: ~3 % of the time) then runs on rank 0."""
+    from ._lib import check, lib
+    from .pipeline import stream_ptr
+    L, m = lib(), pipe.model
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = d_idx.device
+    n, C_ = d_idx.numel(), m.classes
+    nwin = L.dgrp_window_count(n, m.vecsize, pipe.step)
+    a, b = window_share(nwin, world, rank)
+    lo, hi = placement_rows(a, b, nwin, pipe.batch, pipe.step, m.vecsize)
+    local = torch.zeros((max(hi - lo, 1), C_), dtype=torch.float32, device=dev)
+    if b > a:
+        if m.attention:
+            raise NotImplementedError("splitting one record over GPUs is implemented for models without attention")
+        # absolute row indexing: hand the kernel the address row 0 would have
+        base = local.data_ptr() - lo * C_ * 4
+        check(L.dgrp_forward_merge(m.handle, d_idx.data_ptr(), n, pipe.step, pipe.batch, a, b - a, base, None, 0, stream_ptr()),
+              "dgrp_forward_merge")
+    cpu = dist.get_backend() == "gloo"
+    cdev = torch.device("cpu") if cpu else dev
+    span = torch.tensor([lo, hi], dtype=torch.int64, device=cdev)
+    spans = [torch.zeros_like(span) for _ in range(world)]
+    dist.all_gather(spans, span)
+    spans = [(int(s[0]), int(s[1])) for s in spans]
+    cap = max(max(h - l for l, h in spans), 1)
+    send = torch.zeros((cap, C_), dtype=torch.float32, device=cdev)
+    send[: hi - lo] = local[: hi - lo].to(cdev)
+    parts = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+    dist.gather(send, parts, dst=0)
+    if rank != 0:
+        return None
+    out = torch.zeros((n, C_), dtype=torch.float32, device=dev)
+    for (l, h), part in zip(spans, parts):
+        if h > l:
+            torch.maximum(out[l:h], part[: h - l].to(dev), out=out[l:h])
+    return out

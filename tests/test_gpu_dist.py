@@ -45,3 +45,39 @@ def test_gather_records_over_rccl_single_rank():
     assert p.exitcode == 0
     assert [r[3] for r in out] == [0, 0, 1, 1, 2] and [r[0] for r in out] == [5, 30, 10, 50, 7]
     assert nempty == 0 and one == 1.0
+
+
+def _split_worker(rank, world, port, fasta, model, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      DGRP_DIST_BACKEND="gloo")
+    from deepgrp_amd.__main__ import main
+    main(["-b", "7", "predict", model, fasta, "--output", out, "--split_contigs"])
+
+
+def test_split_contigs_two_ranks_on_one_gpu(tmp_path):
+    """--split_contigs with 2 ranks (both on GPU 0, gloo as the transport) gives the same TSV, byte for
+    byte, as a single-process run: the window shares overlap by T - step rows and max-combine exactly."""
+    import torch.multiprocessing as mp
+    from deepgrp_amd import model as dgmodel, synthetic
+    from deepgrp_amd.__main__ import main
+    w = synthetic.trained_weights()
+    mpath = str(tmp_path / "m.hdf5")
+    dgmodel.save_keras_hdf5(mpath, w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, vecsize=200)
+    fa = tmp_path / "two.fa"
+    with open(fa, "wb") as fh:
+        for k, n in enumerate((300_000, 123_457)):
+            raw = synthetic.synthetic_chromosome(n, contig=k, flank=1000)
+            fh.write(b">rec%d\n" % k + b"\n".join(raw[i:i + 70] for i in range(0, len(raw), 70)) + b"\n")
+    single = str(tmp_path / "single.tsv")
+    main(["-b", "7", "predict", mpath, str(fa), "--output", single])
+    split = str(tmp_path / "split.tsv")
+    ctx = mp.get_context("spawn")
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, str(fa), mpath, split)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert open(split).read() == open(single).read()
+    assert open(single).read().count("\n") > 10

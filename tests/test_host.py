@@ -347,3 +347,28 @@ def test_get_segments_walk_matches_golden(orc):
             i = en
             walked.append((st + 5, en + 5, lb))
         np.testing.assert_array_equal(np.array(walked, np.int64).reshape(-1, 3), g[f"all{k}"])
+
+
+def test_window_share_and_placement_rows(orc):
+    """Host arithmetic of the intra-record split: shares tile the windows, and every share's row range
+    contains exactly the rows the oracle's placement gives its windows."""
+    from deepgrp_amd.distributed import placement_rows, window_share
+    for nwin, world in ((0, 3), (5, 4), (16, 2), (1000, 8), (999_996, 8), (77, 5)):
+        cover = []
+        for r in range(world):
+            a, b = window_share(nwin, world, r)
+            assert 0 <= a <= b <= nwin and (a % 16 == 0 or a == nwin)
+            cover += list(range(a, b)) if nwin < 5000 else []
+        if nwin < 5000:
+            assert cover == list(range(nwin))
+    T, s = 200, 50
+    for nwin, B in ((100, 7), (1000, 256), (37, 50), (64, 16)):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                a, b = window_share(nwin, world, r)
+                lo, hi = placement_rows(a, b, nwin, B, s, T)
+                rows = [orc.place_row(w, nwin, B, s) for w in range(a, b)]
+                if rows:
+                    assert lo == min(rows) and hi == max(rows) + T
+                else:
+                    assert (lo, hi) == (0, 0)
