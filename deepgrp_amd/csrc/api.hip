@@ -265,12 +265,12 @@ DGRP_EXPORT int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int
     return DGRP_OK;
 }
 
-// attention keeps avg[t] (fp32 [nw,T,UP]) and the avg half of the logits ([nw,T,C]) between kernels
+// attention keeps avg[t] (fp16 [nw,T,UP]) and the avg half of the logits (fp32 [nw,T,C]) between kernels
 DGRP_EXPORT int64_t dgrp_forward_workspace_bytes(const dgrp_model *m, int64_t nw)
 {
     if (!m || nw < 0) return 0;
     if (!m->attention) return 256;
-    return dgrp_align_up(nw * m->T * (int64_t)m->UP * 4, 256) + dgrp_align_up(nw * m->T * (int64_t)m->C * 4, 256);
+    return dgrp_align_up(nw * m->T * (int64_t)m->UP * 2, 256) + dgrp_align_up(nw * m->T * (int64_t)m->C * 4, 256);
 }
 
 static int forward_common(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch, int64_t w0,
@@ -295,8 +295,8 @@ static int forward_common(const dgrp_model *m, const uint8_t *d_idx, int64_t n, 
                        (long long)dgrp_forward_workspace_bytes(m, nw), (long long)nw);
         return DGRP_ENOMEM;
     }
-    float *avg = (float *)d_work;
-    float *pl = (float *)((char *)d_work + dgrp_align_up(nw * m->T * (int64_t)m->UP * 4, 256));
+    void *avg = d_work;
+    float *pl = (float *)((char *)d_work + dgrp_align_up(nw * m->T * (int64_t)m->UP * 2, 256));
     int rc = dgrp_gru_launch(m, d_idx, n, s, place, w0, nw, 2, pl, avg, stream);
     if (rc) return rc;
     return dgrp_attention_launch(m, s, place, w0, nw, merge, n, avg, pl, d_out, stream);

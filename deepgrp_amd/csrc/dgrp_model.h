@@ -18,7 +18,7 @@ struct dgrp_model {
 
 // rows of LDS the fused kernel may use to pre-merge a workgroup's windows
 int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
-                    int64_t w0, int64_t nw, int mode, float *d_out, float *d_avg, hipStream_t stream);
+                    int64_t w0, int64_t nw, int mode, float *d_out, void *d_avg, hipStream_t stream);
 int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
-                          int merge, int64_t n, const float *d_avg, const float *d_pl, float *d_out,
+                          int merge, int64_t n, const void *d_avg, const float *d_pl, float *d_out,
                           hipStream_t stream);

@@ -43,7 +43,7 @@ struct gru_params {
     const uint4 *pack;
     const float *ffb;
     float *out;           // mode 0: merged [n, C]; mode 1: probs [nw, T, C]; mode 2: logits part [nw, T, C]
-    float *avg;           // mode 2: [nw, T, UP]
+    _Float16 *avg;        // mode 2: [nw, T, UP] fp16
     int T, C, nfrag, mode;
     int Tp;               // T rounded up to 16 (row pitch of the staged sequences)
     int ospan;            // rows of the LDS output image (mode 0), 0 = none
@@ -250,12 +250,12 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             wcol[row * HS] = (_Float16)h[i];
         }
         if (MODE == 2) {
-            // attention: keep avg[t] (fp32) for the second kernel
+            // attention: keep avg[t] (fp16: it is an fp16 MFMA operand everywhere else too) for the second kernel
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int wi = (i & 3) + 8 * (i >> 2) + 4 * khalf;
                 if (wi < nvalid)
-                    p.avg[((wg_w + wi - p.w0) * (int64_t)T + t) * UP + 32 * wave + (lane & 31)] = 0.5f * (h[i] + h[i + 8]);
+                    p.avg[((wg_w + wi - p.w0) * (int64_t)T + t) * UP + 32 * wave + (lane & 31)] = (_Float16)(0.5f * (h[i] + h[i + 8]));
             }
         }
         // ---- Dense on this wave's 32 units: rows r (window) and r+16 (its rc) accumulate ------
@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
 //   a = softmax_t(e);  ctx = sum_t a[t] avg[t];  logits[t] = ctx.W_top + (avg[t].W_bot + b)
 // ------------------------------------------------------------------------------------------
 struct att_params {
-    const float *avg;    // [nw, T, UP]
+    const _Float16 *avg; // [nw, T, UP] fp16
     const float *pl;     // [nw, T, C]  avg[t].W_bot + b  from the GRU kernel
     const float *scale;  // [UP]
     const float *wtop;   // [UP, 16]
@@ -473,56 +473,83 @@ struct att_params {
     int T, C, UP, merge;
 };
 
+// One workgroup (256 threads) per window, ONE pass over the window's avg[t] tile (read from HBM once):
+// tiles of 64 time steps are staged in LDS; scores e[t] = sum_k scale[k] tanh(q[k] + avg[t,k]) are
+// computed with lane <-> t (each wave a quarter of the units), the softmax over t is kept online
+// (running max / sum, context rescaled per tile), the context update runs with thread <-> unit.
+#define ATT_TT 64
 __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *q = reinterpret_cast<float *>(smem);          // [UP]
-    float *ctx = q + p.UP;                               // [UP]
-    float *e = ctx + p.UP;                               // [T]
-    float *red = e + p.T;                                // [16]
-    float *cl = red + 16;                                // [16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = p.T, UP = p.UP, C = p.C;
-    const int64_t wl = blockIdx.x;                       // window relative to w0
-    const float *avg = p.avg + wl * (int64_t)T * UP;
+    const int TS = UP + 8;                                   // padded tile row (halves): conflict-free column walks
+    _Float16 *tile = reinterpret_cast<_Float16 *>(smem);     // [ATT_TT][TS]
+    float *q = reinterpret_cast<float *>(tile + ATT_TT * TS);   // [UP]
+    float *sc = q + UP;                                       // [UP] scale
+    float *ctx = sc + UP;                                     // [UP]
+    float *epart = ctx + UP;                                  // [4][ATT_TT]
+    float *pw = epart + 4 * ATT_TT;                           // [ATT_TT] softmax numerators of the tile
+    float *red = pw + ATT_TT;                                 // [8]
+    float *cl = red + 8;                                      // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t wl = blockIdx.x;
+    const _Float16 *avg = p.avg + wl * (int64_t)T * UP;
 
-    for (int k = tid; k < UP; k += 256) q[k] = avg[(int64_t)(T - 1) * UP + k];
-    __syncthreads();
-    for (int t = wave; t < T; t += 4) {
-        float acc = 0.0f;
-        for (int k = lane; k < UP; k += 64) acc += p.scale[k] * fast_tanh(q[k] + avg[(int64_t)t * UP + k]);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) e[t] = acc;
-    }
-    __syncthreads();
-    // softmax over t
-    float m = -INFINITY;
-    for (int t = tid; t < T; t += 256) m = fmaxf(m, e[t]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float ssum = 0.0f;
-    for (int t = tid; t < T; t += 256) { float v = __expf(e[t] - m); e[t] = v; ssum += v; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o);
-    __syncthreads();
-    if (lane == 0) red[8 + wave] = ssum;
-    __syncthreads();
-    const float inv = 1.0f / (red[8] + red[9] + red[10] + red[11]);
     for (int k = tid; k < UP; k += 256) {
-        float acc = 0.0f;
-        for (int t = 0; t < T; ++t) acc += e[t] * avg[(int64_t)t * UP + k];
-        ctx[k] = acc * inv;
+        q[k] = (float)avg[(int64_t)(T - 1) * UP + k];         // Average of the two final states = avg[T-1]
+        sc[k] = p.scale[k];
+        ctx[k] = 0.0f;
+    }
+    float run_m = -INFINITY, run_l = 0.0f;                    // online softmax state (same value in every thread)
+    const int kq = UP / 4;                                    // units per wave in the score phase
+    for (int t0 = 0; t0 < T; t0 += ATT_TT) {
+        const int nt = min(ATT_TT, T - t0);
+        __syncthreads();                                      // previous tile fully consumed (and q/sc/ctx initialised)
+        // stage [nt][UP] halves: 16-byte chunks, coalesced
+        const int chunks_per_row = UP / 8;
+        for (int i = tid; i < nt * chunks_per_row; i += 256) {
+            const int r = i / chunks_per_row, c8 = i - r * chunks_per_row;
+            *reinterpret_cast<uint4 *>(tile + r * TS + c8 * 8) =
+                *reinterpret_cast<const uint4 *>(avg + (int64_t)(t0 + r) * UP + c8 * 8);
+        }
+        __syncthreads();
+        // scores: lane <-> t, wave <-> quarter of the units
+        float e = 0.0f;
+        if (lane < nt) {
+            const _Float16 *row = tile + lane * TS + wave * kq;
+            const float *qq = q + wave * kq, *ss = sc + wave * kq;
+            for (int k = 0; k < kq; ++k) e += ss[k] * fast_tanh(qq[k] + (float)row[k]);
+        }
+        epart[wave * ATT_TT + lane] = e;
+        __syncthreads();
+        float et = lane < nt ? epart[lane] + epart[ATT_TT + lane] + epart[2 * ATT_TT + lane] + epart[3 * ATT_TT + lane] : -INFINITY;
+        float tm = et;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+        const float new_m = fmaxf(run_m, tm);
+        const float alpha = __expf(run_m - new_m);            // 0 on the first tile (run_m = -inf)
+        const float pt = lane < nt ? __expf(et - new_m) : 0.0f;
+        float ps = pt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
+        run_l = run_l * alpha + ps;
+        run_m = new_m;
+        if (wave == 0) pw[lane] = pt;
+        __syncthreads();
+        // context: thread <-> unit (two halves of the tile's time steps when UP <= 128)
+        for (int k = tid; k < UP; k += 256) {
+            float acc = 0.0f;
+            for (int t = 0; t < nt; ++t) acc += pw[t] * (float)tile[t * TS + k];
+            ctx[k] = ctx[k] * alpha + acc;
+        }
     }
     __syncthreads();
+    const float inv = 1.0f / run_l;
     if (tid < 16) {
         float acc = 0.0f;
         if (tid < C)
             for (int k = 0; k < UP; ++k) acc += ctx[k] * p.wtop[k * 16 + tid];
-        cl[tid] = acc;
+        cl[tid] = acc * inv;
     }
     __syncthreads();
     const int64_t w = p.w0 + wl;
@@ -587,12 +614,12 @@ static int launch_lstm(const gru_params &p, int64_t groups, size_t lds, hipStrea
 }
 
 int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
-                    int64_t w0, int64_t nw, int mode, float *d_out, float *d_avg, hipStream_t stream)
+                    int64_t w0, int64_t nw, int mode, float *d_out, void *d_avg, hipStream_t stream)
 {
     if (nw <= 0) return DGRP_OK;
     gru_params p;
     p.idx = d_idx; p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
-    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = d_avg;
+    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = (_Float16 *)d_avg;
     p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = mode;
     p.Tp = (int)dgrp_align_up(m->T, 16);
     const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
@@ -634,15 +661,15 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
 }
 
 int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
-                          int merge, int64_t n, const float *d_avg, const float *d_pl, float *d_out,
+                          int merge, int64_t n, const void *d_avg, const float *d_pl, float *d_out,
                           hipStream_t stream)
 {
     if (nw <= 0) return DGRP_OK;
     att_params p;
-    p.avg = d_avg; p.pl = d_pl; p.scale = m->d_scale; p.wtop = m->d_wtop; p.out = d_out;
+    p.avg = (const _Float16 *)d_avg; p.pl = d_pl; p.scale = m->d_scale; p.wtop = m->d_wtop; p.out = d_out;
     p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
     p.T = m->T; p.C = m->C; p.UP = m->UP; p.merge = merge;
-    const size_t lds = (size_t)(2 * m->UP + m->T + 32) * sizeof(float);
+    const size_t lds = (size_t)ATT_TT * (m->UP + 8) * 2 + (size_t)(3 * m->UP + 4 * ATT_TT + ATT_TT + 8 + 16) * sizeof(float);
     DGRP_REQUIRE(nw < (1ll << 31), "too many windows in one launch");
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)nw), dim3(256), lds, stream, p);
     DGRP_LAUNCH_CHECK();

@@ -168,7 +168,7 @@ class ContigPipeline:
         chunk = self.chunk_windows
         if m.attention:
             # keep the avg[t] spill of one launch below ~2 GiB
-            per = m.vecsize * (((m.units + 31) // 32) * 32 + m.classes) * 4
+            per = m.vecsize * (((m.units + 31) // 32) * 32 * 2 + m.classes * 4)
             chunk = max(16, min(chunk, (2 << 30) // per // 16 * 16))
         work = None
         w0 = 0

@@ -1,0 +1,24 @@
+"""Throughput of the other BASELINE model shapes (merged-probabilities stage only)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepgrp_amd import synthetic
+from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence
+
+cases = [("defaults.toml  u=60  T=342 s=50 attention", 60, 342, 50, True, 20e6),
+         ("cfg5           u=256 T=500 s=25 attention", 256, 500, 25, True, 5e6),
+         ("               u=256 T=500 s=25 no attention", 256, 500, 25, False, 5e6),
+         ("               u=128 T=200 s=50 attention", 128, 200, 50, True, 20e6),
+         ("cfg2           u=128 T=200 s=50", 128, 200, 50, False, 20e6),
+         ("               u=64  T=200 s=50", 64, 200, 50, False, 20e6),
+         ("               u=32  T=150 s=50 (Options defaults)", 32, 150, 50, False, 20e6)]
+for name, u, T, s, att, n in cases:
+    w = synthetic.synthetic_weights(u, 5, att, seed=7, gain=1.5)
+    m = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], T)
+    st, d_idx = upload_sequence(synthetic.synthetic_chromosome(int(n)))
+    pipe = ContigPipeline(m, s)
+    pipe.merged(d_idx); torch.cuda.synchronize()
+    t0 = time.perf_counter(); pipe.merged(d_idx); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    fl = (12 * u * u * T + 2 * (2 * u if att else u) * 5 * T + (6 * u * T if att else 0)) / s
+    print(f"{name:52s} {n/1e6:4.0f} Mbp: {dt*1e3:8.1f} ms  {n/dt/1e6:7.1f} Mbp/s  {fl*n/dt/1e12:6.1f} TFLOP/s", flush=True)
+    m.close(); del d_idx, pipe; torch.cuda.empty_cache()
