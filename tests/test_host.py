@@ -372,3 +372,39 @@ def test_window_share_and_placement_rows(orc):
                     assert lo == min(rows) and hi == max(rows) + T
                 else:
                     assert (lo, hi) == (0, 0)
+
+
+def test_fast_fasta_reader_equals_reference_loop(tmp_path):
+    """deepgrp_amd.fasta.read_multi_fasta_file (bytes.translate fast path + per-record fallback) against
+    the reference's line loop (deepgrp/__main__.py:20-43) incl. where exceptions are raised."""
+    from deepgrp_amd.fasta import read_multi_fasta_file, read_multi_fasta_lines
+    rng = np.random.default_rng(0)
+
+    def seq(n):
+        return "".join(rng.choice(list("ACGTNacgtn"), size=n))
+
+    def wrap(s, w=60, nl="\n"):
+        return nl.join(s[i:i + w] for i in range(0, len(s), w))
+
+    cases = [">a\n" + wrap(seq(500)) + "\n>b desc\n" + wrap(seq(130)) + "\n", "junk\nACGT\n>a\n" + wrap(seq(100)) + "\n",
+             ">a\r\n" + wrap(seq(200), 60, "\r\n") + "\r\n>b\r\nAC\r\n", ">a\n" + wrap(seq(100)) + "\n\n>b\nAC\n",
+             ">a\nAC GT\n  >b\nTT\n>c\n\tGG \n", ">a\nACGT", ">a\nACGT\n>\nGG\n>c\nTT\n", ">a\n>b\n>c\nA\n", "",
+             ">only header\n", ">a\nAC\rGT\n", ">a\nACGT\n\n", "\n>a\nAC\n", ">a\n\xc3\xa4CGT\n"]
+    for i, text in enumerate(cases):
+        path = tmp_path / f"c{i}.fa"
+        path.write_bytes(text.encode("latin-1"))
+
+        def run(fn):
+            out, err = [], None
+            try:
+                for h, s in fn():
+                    out.append((h, s.decode() if isinstance(s, bytes) else s))
+            except Exception as e:      # noqa: BLE001
+                err = type(e).__name__
+            return out, err
+
+        def ref():
+            with open(path, "r") as fh:
+                yield from read_multi_fasta_lines(fh)
+
+        assert run(lambda: read_multi_fasta_file(str(path))) == run(ref), f"case {i}: {text[:30]!r}"
