@@ -29,6 +29,7 @@
 // on the VALU pipe are of the same order; two workgroups per CU let one's MFMAs
 // overlap the other's gate math.
 #include "dgrp_model.h"
+#include <vector>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,6 +48,8 @@ struct gru_params {
     int T, C, nfrag, mode;
     int Tp;               // T rounded up to 16 (row pitch of the staged sequences)
     int ospan;            // rows of the LDS output image (mode 0), 0 = none
+    int delay, delay_mode; // experiment: one-time start delay of the second workgroup slot
+    uint64_t *stamps;
 };
 
 // The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
@@ -54,6 +57,15 @@ struct gru_params {
 // tanh(x) = 1 - 2/(1 + 2^(2 x log2 e)).
 __device__ __forceinline__ float sigmoid_from_scaled(float a) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
 __device__ __forceinline__ float tanh_from_scaled(float a) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
+// Two gate values at a time: the transcendentals are scalar instructions, the "1 +" between them is one
+// packed add (v_pk_add_f32 does two lanes' worth per issue slot).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 rcp1p_exp2_pair(float a0, float a1)
+{
+    f32x2 e = { __builtin_amdgcn_exp2f(a0), __builtin_amdgcn_exp2f(a1) };
+    e = e + 1.0f;
+    return f32x2{ __builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y) };
+}
 __device__ __forceinline__ float fast_tanh(float x) { return tanh_from_scaled(2.8853900817779268f * x); }
 
 // rotate within each row of 16 lanes (DPP row_ror): an all-reduce over the 16 class lanes in 4 steps
@@ -71,12 +83,31 @@ __device__ __forceinline__ float row_allsum(float x)
     x += row_ror<8>(x); x += row_ror<4>(x); x += row_ror<2>(x); return x + row_ror<1>(x);
 }
 
+// The two destinations of the max-merge as distinct instructions (ds_max_u32 / global_atomic_umax): left to
+// atomicMax on generic pointers the compiler merges both branches into one flat atomic, whose latency then
+// sits in front of every later LDS wait of the wave.
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(1))) unsigned glb_u32;
+__device__ __forceinline__ void lds_atomic_max(unsigned *p, unsigned v)
+{
+    (void)__hip_atomic_fetch_max((lds_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void global_atomic_max(unsigned *p, unsigned v)
+{
+    (void)__hip_atomic_fetch_max((glb_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // LDS carve (bytes) -- shared by host and device
 __host__ __device__ static inline int gru_lds_hbuf(int UP) { return 2 * 32 * (UP + 8) * 2; }
 __host__ __device__ static inline int gru_lds_dpart(int NW) { return 2 * NW * 64 * 16; }
 __host__ __device__ static inline int gru_lds_seq(int Tp) { return DGRP_WG_WINDOWS * Tp; }
 __host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 8 + DGRP_WG_WINDOWS * 4; }
 
+#ifdef DGRP_STAMP
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += (uint32_t)(now_ - stamp_prev); stamp_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #ifndef DGRP_PIPE
 #define DGRP_PIPE 1
 #endif
@@ -96,6 +127,10 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     int *rowoff = reinterpret_cast<int *>(row0s + DGRP_WG_WINDOWS);
     unsigned *obuf = reinterpret_cast<unsigned *>(rowoff + DGRP_WG_WINDOWS);
 
+#ifdef DGRP_STAMP
+    const uint64_t stamp_entry = __builtin_amdgcn_s_memtime();
+    const uint64_t stamp_rentry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,6 +138,17 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     const int64_t wg_w = p.w0 + (int64_t)blockIdx.x * DGRP_WG_WINDOWS;   // first window of this workgroup
     const int nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - wg_w);
 
+    if (p.delay > 0 && blockIdx.x < 512) {
+        bool late;
+        if (p.delay_mode == 0) late = (blockIdx.x >> 8) & 1;
+        else {
+            if (tid == 0) rowoff[0] = __builtin_amdgcn_s_getreg(6148) & 1;      // HW_ID.wave_id parity
+            __syncthreads();
+            late = rowoff[0];
+            __syncthreads();
+        }
+        if (late) for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     // ---- resident B fragments ------------------------------------------------------------
     const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
     half8 Bz[KS + 1], Br[KS + 1], Bg[KS + 1], Bxh, Bd_hi, Bd_lo;
@@ -162,9 +208,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     // Softmax + merge of step t's partial logits.  The 16x16 logit tile (window = 4*(lane>>4) + reg,
     // class = lane & 15) is split by accumulator register over the waves, one value per lane.
     auto finish_step = [&](int t) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            if (reg % NW != wave) continue;
+        for (int reg = wave; reg < 4; reg += NW) {
             const float *dp = dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
             float sum = dp[0];
 #pragma unroll
@@ -181,10 +225,10 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
                 if (MODE == 0) {
                     const int off = rowoff[wi];
                     if (off >= 0) {
-                        atomicMax(&obuf[(off + t) * C + cls], __float_as_uint(val));
+                        lds_atomic_max(obuf + (off + t) * C + cls, __float_as_uint(val));
                     } else {
                         const int64_t row = row0s[wi] + t;
-                        if (row < p.n) atomicMax(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
+                        if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
                     }
                 } else {
                     p.out[(row0s[wi] + t) * C + cls] = val;
@@ -192,10 +236,35 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             }
         }
     };
+    // Dense on this wave's 32 units of the hidden tile `hb`: rows r (window) and r+16 (its rc) accumulate
+    // (= the Average); issue only -- the partial logits are stored by dense_store once the MFMAs are done.
+    const int doff = (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
+    auto dense_issue = [&](const _Float16 *hb) -> f32x4 {
+        const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff);
+        const half8 a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
+    };
+    auto dense_store = [&](int t, const f32x4 &d) {
+        float *dw = dpart + ((size_t)(t & 1) * 4 * NW + wave) * 64 + lane;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) dw[reg * NW * 64] = d[reg];
+    };
 
+#ifdef DGRP_STAMP
+    uint32_t stamp_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint64_t stamp_prev = __builtin_amdgcn_s_memtime();
+    const uint64_t stamp_t0 = stamp_prev, stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // Step t, in program order (the matrix pipe runs behind the wave's instruction stream, so whatever is
+    // issued after a group of MFMAs executes in their shadow):
+    //   loads of h_{t-1} | r chain + Dense(t-1) MFMAs | softmax/merge of step t-2 | g chain + sigmoid(r) |
+    //   z chain + r*g, candidate input projection, tanh | store Dense(t-1) partials | sigmoid(z), blend,
+    //   publish h_t | barrier
     for (int t = 0; t < T; ++t) {
-        if (t > 0) finish_step(t - 1);
-
+        STAMP(0);
         // ---- A operand of the input k-step: one-hot(base) | 1 ------------------------------
         uint32_t b = myseq[dir ? T - 1 - t : t];
         if (dir) b = b < 4 ? 3 - b : 4;                      // complement table [3,2,1,0,4], model.py:233-237
@@ -204,9 +273,6 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         const uint4 xu = make_uint4(sel == 0 ? one : 0u, sel == 1 ? one : 0u, (sel == 2 ? one : 0u) | 0x3C000000u, 0u);
         const half8 xa = __builtin_bit_cast(half8, xu);
 
-        // Software pipeline inside the wave (the matrix pipe and the VALU only overlap for instructions
-        // that are interleaved in program order): r chain | g chain + sigmoid(r) | z chain + r*g | input
-        // projection of the candidate.
         const _Float16 *arow = hcur + r * HS + 8 * khalf;
         half8 af[KS];
 #pragma unroll
@@ -214,6 +280,13 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Br[KS], zero16, 0, 0, 0);
 #pragma unroll
         for (int k = 0; k < KS; ++k) ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], Br[k], ar, 0, 0, 0);
+        f32x4 dpl = zero4;
+        if (t > 0) dpl = dense_issue(hcur);
+        if (PIPE) __builtin_amdgcn_sched_barrier(0);
+        STAMP(1);
+        if (t > 1) finish_step(t - 2);
+        if (PIPE) __builtin_amdgcn_sched_barrier(0);
+        STAMP(2);
         f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bg[KS], zero16, 0, 0, 0);
         float rr[16];
 #pragma unroll
@@ -221,26 +294,44 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], Bg[k], ag, 0, 0, 0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = k * 16 / KS; i < (k + 1) * 16 / KS; ++i) rr[i] = sigmoid_from_scaled(ar[i]);
+            for (int i = 2 * (k * 8 / KS); i < 2 * ((k + 1) * 8 / KS); i += 2) {
+                const f32x2 q = rcp1p_exp2_pair(ar[i], ar[i + 1]);
+                rr[i] = q.x; rr[i + 1] = q.y;
+            }
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP(3);
         f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bz[KS], zero16, 0, 0, 0);
+        // z chain: its first half hides r * g, then the candidate's input projection is issued and the
+        // second half hides the tanh
+        constexpr int KH = KS / 2;
+        float hh[16];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const half8 bz = ZSTREAM ? __builtin_bit_cast(half8, mypack[(size_t)k * 64]) : Bz[k];
             az = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], bz, az, 0, 0, 0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
+            if (k < KH) {
 #pragma unroll
-            for (int i = k * 16 / KS; i < (k + 1) * 16 / KS; ++i) ag[i] *= rr[i];          // r * (h.U_h + b_rec_h)
+                for (int i = k * 16 / KH; i < (k + 1) * 16 / KH; ++i) ag[i] *= rr[i];      // r * (h.U_h + b_rec_h)
+                if (k == KH - 1) ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bxh, ag, 0, 0, 0);    // + x.W_h + b_in_h
+            } else {
+#pragma unroll
+                for (int i = 2 * ((k - KH) * 8 / (KS - KH)); i < 2 * ((k - KH + 1) * 8 / (KS - KH)); i += 2) {
+                    const f32x2 q = 1.0f - 2.0f * rcp1p_exp2_pair(ag[i], ag[i + 1]);
+                    hh[i] = q.x; hh[i + 1] = q.y;
+                }
+            }
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
-        ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bxh, ag, 0, 0, 0);    // + x.W_h + b_in_h
+        if (t > 0) dense_store(t - 1, dpl);
+        STAMP(4);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) az[i] = sigmoid_from_scaled(az[i]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float hh = tanh_from_scaled(ag[i]);
-            h[i] = hh + az[i] * (h[i] - hh);                                 // z*h + (1-z)*hh
+        for (int i = 0; i < 16; i += 2) {
+            const f32x2 z = rcp1p_exp2_pair(az[i], az[i + 1]);
+            const f32x2 hv = { h[i], h[i + 1] }, cv = { hh[i], hh[i + 1] };
+            const f32x2 hn = cv + z * (hv - cv);                               // z*h + (1-z)*hh
+            h[i] = hn.x; h[i + 1] = hn.y;
         }
         // ---- publish h_t (fp16) for the next step's A operand ------------------------------
         _Float16 *wcol = hnxt + 32 * wave + (lane & 31);
@@ -258,23 +349,29 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
                     p.avg[((wg_w + wi - p.w0) * (int64_t)T + t) * UP + 32 * wave + (lane & 31)] = (_Float16)(0.5f * (h[i] + h[i + 8]));
             }
         }
-        // ---- Dense on this wave's 32 units: rows r (window) and r+16 (its rc) accumulate ------
-        {
-            const _Float16 *drow = hnxt + (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
-            const half8 a0 = *reinterpret_cast<const half8 *>(drow);
-            const half8 a1 = *reinterpret_cast<const half8 *>(drow + 16 * HS);
-            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
-            float *dw = dpart + ((size_t)(t & 1) * 4 * NW + wave) * 64 + lane;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) dw[reg * NW * 64] = d[reg];
-        }
+        STAMP(5);
         __syncthreads();
+        STAMP(6);
         _Float16 *tmp = hcur; hcur = hnxt; hnxt = tmp;
     }
-    finish_step(T - 1);
+#ifdef DGRP_STAMP
+    if (p.stamps && lane == 0) {
+        uint64_t *o = p.stamps + ((size_t)blockIdx.x * NW + wave) * 16;
+        for (int k = 0; k < 8; ++k) o[k] = stamp_acc[k];
+        o[8] = __builtin_amdgcn_s_memtime() - stamp_t0;
+        o[9] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        o[10] = stamp_t0 - stamp_entry;
+        o[11] = __builtin_amdgcn_s_getreg(6148 | (11 << 11)) ;   // HW_ID low 12 bits
+    }
+#endif
+    // drain: Dense of the last step, the two outstanding softmax/merge steps
+    {
+        const f32x4 dpl = dense_issue(hcur);
+        if (T > 1) finish_step(T - 2);
+        dense_store(T - 1, dpl);
+        __syncthreads();
+        finish_step(T - 1);
+    }
 
     if (MODE == 0 && p.ospan > 0) {
         __syncthreads();
@@ -283,9 +380,18 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         const int64_t lim = (p.n - lo) * C;
         for (int i = tid; i < p.ospan * C; i += 64 * NW) {
             const unsigned v = obuf[i];
-            if (v != 0u && i < lim) atomicMax(gout + i, v);
+            if (v != 0u && i < lim) global_atomic_max(gout + i, v);
         }
     }
+#ifdef DGRP_STAMP
+    if (p.stamps && lane == 0) {
+        uint64_t *o = p.stamps + ((size_t)blockIdx.x * NW + wave) * 16;
+        o[11] = __builtin_amdgcn_s_memtime() - stamp_entry;
+        o[12] = stamp_rentry;
+        o[13] = __builtin_amdgcn_s_memrealtime();
+        o[14] = __builtin_amdgcn_s_getreg((15 << 11) | 4);     // HW_ID[15:0]
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -381,10 +487,10 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
                 if (MODE == 0) {
                     const int off = rowoff[wi];
                     if (off >= 0) {
-                        atomicMax(&obuf[(off + t) * C + cls], __float_as_uint(val));
+                        lds_atomic_max(obuf + (off + t) * C + cls, __float_as_uint(val));
                     } else {
                         const int64_t row = row0s[wi] + t;
-                        if (row < p.n) atomicMax(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
+                        if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
                     }
                 } else {
                     p.out[(row0s[wi] + t) * C + cls] = val;
@@ -451,7 +557,7 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
         const int64_t lim = (p.n - lo) * C;
         for (int i = tid; i < p.ospan * C; i += 64 * NW) {
             const unsigned v = obuf[i];
-            if (v != 0u && i < lim) atomicMax(gout + i, v);
+            if (v != 0u && i < lim) global_atomic_max(gout + i, v);
         }
     }
 }
@@ -622,6 +728,19 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = (_Float16 *)d_avg;
     p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = mode;
     p.Tp = (int)dgrp_align_up(m->T, 16);
+    p.stamps = nullptr;
+#ifdef DGRP_STAMP
+    static uint64_t *d_stamps = nullptr;
+    const int64_t ngroups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
+    const size_t stamp_bytes = (size_t)ngroups * m->NW * 16 * 8;
+    if (getenv("DGRP_STAMP_DUMP")) {
+        if (d_stamps) (void)hipFree(d_stamps);
+        DGRP_HIP(hipMalloc((void **)&d_stamps, stamp_bytes));
+        DGRP_HIP(hipMemset(d_stamps, 0, stamp_bytes));
+        p.stamps = d_stamps;
+    }
+#endif
+    { const char *e = getenv("DGRP_GRU_DELAY"); p.delay = e ? atoi(e) : 0; e = getenv("DGRP_GRU_DELAY_MODE"); p.delay_mode = e ? atoi(e) : 0; }
     const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
     p.ospan = 0;
     if (mode == 0) {
@@ -645,6 +764,17 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
             return DGRP_EINVAL;
         }
     }
+#ifdef DGRP_STAMP
+    if (p.stamps && m->NW == 4) {
+        int rc = launch_gru<4>(p, groups, lds, stream);
+        (void)hipStreamSynchronize(stream);
+        std::vector<uint64_t> hst(stamp_bytes / 8);
+        (void)hipMemcpy(hst.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost);
+        FILE *f = fopen(getenv("DGRP_STAMP_DUMP"), "wb");
+        if (f) { fwrite(hst.data(), 1, stamp_bytes, f); fclose(f); }
+        return rc;
+    }
+#endif
     switch (m->NW) {
     case 1: return launch_gru<1>(p, groups, lds, stream);
     case 2: return launch_gru<2>(p, groups, lds, stream);
