@@ -34,6 +34,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 #define DGRP_WG_WINDOWS 16
 
@@ -237,11 +238,16 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         }
     };
     // Dense on this wave's 32 units of the hidden tile `hb`: rows r (window) and r+16 (its rc) accumulate
-    // (= the Average); issue only -- the partial logits are stored by dense_store once the MFMAs are done.
+    // (= the Average; the attention pre-pass also stores it, step tt); issue only -- the partial logits are stored by dense_store once the MFMAs are done.
     const int doff = (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
-    auto dense_issue = [&](const _Float16 *hb) -> f32x4 {
+    auto dense_issue = [&](const _Float16 *hb, int tt) -> f32x4 {
         const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff);
         const half8 a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
+        if (MODE == 2 && (lane & 15) < nvalid) {
+            // attention: keep avg[t] (fp16: it is an fp16 MFMA operand everywhere else too) for the second kernel
+            const half8 av = (a0 + a1) * (_Float16)0.5f;
+            *reinterpret_cast<half8 *>(p.avg + ((wg_w + (lane & 15) - p.w0) * (int64_t)T + tt) * UP + 32 * wave + 8 * (lane >> 4)) = av;
+        }
         f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
@@ -277,21 +283,21 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         half8 af[KS];
 #pragma unroll
         for (int k = 0; k < KS; ++k) af[k] = *reinterpret_cast<const half8 *>(arow + 16 * k);
-        f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Br[KS], zero16, 0, 0, 0);
+        f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
 #pragma unroll
-        for (int k = 0; k < KS; ++k) ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], Br[k], ar, 0, 0, 0);
+        for (int k = 0; k < KS; ++k) ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], af[k], ar, 0, 0, 0);
         f32x4 dpl = zero4;
-        if (t > 0) dpl = dense_issue(hcur);
+        if (t > 0) dpl = dense_issue(hcur, t - 1);
         if (PIPE) __builtin_amdgcn_sched_barrier(0);
         STAMP(1);
         if (t > 1) finish_step(t - 2);
         if (PIPE) __builtin_amdgcn_sched_barrier(0);
         STAMP(2);
-        f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bg[KS], zero16, 0, 0, 0);
+        f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[KS], xa, zero16, 0, 0, 0);
         float rr[16];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], Bg[k], ag, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], af[k], ag, 0, 0, 0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 2 * (k * 8 / KS); i < 2 * ((k + 1) * 8 / KS); i += 2) {
@@ -301,7 +307,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
         STAMP(3);
-        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bz[KS], zero16, 0, 0, 0);
+        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[KS], xa, zero16, 0, 0, 0);
         // z chain: its first half hides r * g, then the candidate's input projection is issued and the
         // second half hides the tanh
         constexpr int KH = KS / 2;
@@ -309,12 +315,12 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const half8 bz = ZSTREAM ? __builtin_bit_cast(half8, mypack[(size_t)k * 64]) : Bz[k];
-            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[k], bz, az, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(bz, af[k], az, 0, 0, 0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
             if (k < KH) {
 #pragma unroll
                 for (int i = k * 16 / KH; i < (k + 1) * 16 / KH; ++i) ag[i] *= rr[i];      // r * (h.U_h + b_rec_h)
-                if (k == KH - 1) ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(xa, Bxh, ag, 0, 0, 0);    // + x.W_h + b_in_h
+                if (k == KH - 1) ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, ag, 0, 0, 0);    // + x.W_h + b_in_h
             } else {
 #pragma unroll
                 for (int i = 2 * ((k - KH) * 8 / (KS - KH)); i < 2 * ((k - KH + 1) * 8 / (KS - KH)); i += 2) {
@@ -333,21 +339,13 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             const f32x2 hn = cv + z * (hv - cv);                               // z*h + (1-z)*hh
             h[i] = hn.x; h[i + 1] = hn.y;
         }
-        // ---- publish h_t (fp16) for the next step's A operand ------------------------------
-        _Float16 *wcol = hnxt + 32 * wave + (lane & 31);
+        // ---- publish h_t (fp16) for the next step's B operand: a lane holds 4 x 4 consecutive units of
+        // one row (transposed tile), i.e. four 8-byte stores
+        _Float16 *wrow = hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * khalf;            // 32x32 C/D layout
-            wcol[row * HS] = (_Float16)h[i];
-        }
-        if (MODE == 2) {
-            // attention: keep avg[t] (fp16: it is an fp16 MFMA operand everywhere else too) for the second kernel
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int wi = (i & 3) + 8 * (i >> 2) + 4 * khalf;
-                if (wi < nvalid)
-                    p.avg[((wg_w + wi - p.w0) * (int64_t)T + t) * UP + 32 * wave + (lane & 31)] = (_Float16)(0.5f * (h[i] + h[i + 8]));
-            }
+        for (int q = 0; q < 4; ++q) {
+            const half4 hv = { (_Float16)h[4 * q], (_Float16)h[4 * q + 1], (_Float16)h[4 * q + 2], (_Float16)h[4 * q + 3] };
+            *reinterpret_cast<half4 *>(wrow + 8 * q) = hv;
         }
         STAMP(5);
         __syncthreads();
@@ -366,7 +364,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 #endif
     // drain: Dense of the last step, the two outstanding softmax/merge steps
     {
-        const f32x4 dpl = dense_issue(hcur);
+        const f32x4 dpl = dense_issue(hcur, T - 1);
         if (T > 1) finish_step(T - 2);
         dense_store(T - 1, dpl);
         __syncthreads();
