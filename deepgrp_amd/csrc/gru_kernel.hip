@@ -75,9 +75,18 @@ __device__ __forceinline__ float row_ror(float x)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 | N, 0xf, 0xf, false));
 }
+// max(x, x rotated by N) as ONE v_max_f32_dpp (fmaxf on a DPP move costs a zero fill, the move and two
+// canonicalising maxes); the s_nop covers the VALU-write -> DPP-read hazard the assembler does not see.
+template <int N>
+__device__ __forceinline__ float row_max_ror(float x)
+{
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(N));
+    return r;
+}
 __device__ __forceinline__ float row_allmax(float x)
 {
-    x = fmaxf(x, row_ror<8>(x)); x = fmaxf(x, row_ror<4>(x)); x = fmaxf(x, row_ror<2>(x)); return fmaxf(x, row_ror<1>(x));
+    return row_max_ror<1>(row_max_ror<2>(row_max_ror<4>(row_max_ror<8>(x))));
 }
 __device__ __forceinline__ float row_allsum(float x)
 {
@@ -196,9 +205,9 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     const int khalf = lane >> 5;        // which 8 of a 16-deep k-step this lane feeds
     const uint8_t *myseq = seqs + wi_a * p.Tp;
 
-    float h[16];
+    f32x2 h[8];                         // fp32 master state, pairs of adjacent units (packed VALU operands)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) h[i] = 0.0f;
+    for (int i = 0; i < 8; ++i) h[i] = f32x2{ 0.0f, 0.0f };
 
     _Float16 *hcur = hbuf, *hnxt = hbuf + 32 * HS;
     const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -294,15 +303,14 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         if (PIPE) __builtin_amdgcn_sched_barrier(0);
         STAMP(2);
         f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[KS], xa, zero16, 0, 0, 0);
-        float rr[16];
+        f32x2 rr[8];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], af[k], ag, 0, 0, 0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 2 * (k * 8 / KS); i < 2 * ((k + 1) * 8 / KS); i += 2) {
-                const f32x2 q = rcp1p_exp2_pair(ar[i], ar[i + 1]);
-                rr[i] = q.x; rr[i + 1] = q.y;
+                rr[i / 2] = rcp1p_exp2_pair(ar[i], ar[i + 1]);
             }
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
@@ -311,7 +319,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         // z chain: its first half hides r * g, then the candidate's input projection is issued and the
         // second half hides the tanh
         constexpr int KH = KS / 2;
-        float hh[16];
+        f32x2 hh[8];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const half8 bz = ZSTREAM ? __builtin_bit_cast(half8, mypack[(size_t)k * 64]) : Bz[k];
@@ -319,13 +327,15 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
             if (k < KH) {
 #pragma unroll
-                for (int i = k * 16 / KH; i < (k + 1) * 16 / KH; ++i) ag[i] *= rr[i];      // r * (h.U_h + b_rec_h)
+                for (int i = 2 * (k * 8 / KH); i < 2 * ((k + 1) * 8 / KH); i += 2) {      // r * (h.U_h + b_rec_h)
+                    const f32x2 pr = f32x2{ ag[i], ag[i + 1] } * rr[i / 2];
+                    ag[i] = pr.x; ag[i + 1] = pr.y;
+                }
                 if (k == KH - 1) ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, ag, 0, 0, 0);    // + x.W_h + b_in_h
             } else {
 #pragma unroll
                 for (int i = 2 * ((k - KH) * 8 / (KS - KH)); i < 2 * ((k - KH + 1) * 8 / (KS - KH)); i += 2) {
-                    const f32x2 q = 1.0f - 2.0f * rcp1p_exp2_pair(ag[i], ag[i + 1]);
-                    hh[i] = q.x; hh[i + 1] = q.y;
+                    hh[i / 2] = 1.0f - 2.0f * rcp1p_exp2_pair(ag[i], ag[i + 1]);
                 }
             }
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
@@ -333,18 +343,16 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         if (t > 0) dense_store(t - 1, dpl);
         STAMP(4);
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            const f32x2 z = rcp1p_exp2_pair(az[i], az[i + 1]);
-            const f32x2 hv = { h[i], h[i + 1] }, cv = { hh[i], hh[i + 1] };
-            const f32x2 hn = cv + z * (hv - cv);                               // z*h + (1-z)*hh
-            h[i] = hn.x; h[i + 1] = hn.y;
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 z = rcp1p_exp2_pair(az[2 * i], az[2 * i + 1]);
+            h[i] = hh[i] + z * (h[i] - hh[i]);                                 // z*h + (1-z)*hh
         }
         // ---- publish h_t (fp16) for the next step's B operand: a lane holds 4 x 4 consecutive units of
         // one row (transposed tile), i.e. four 8-byte stores
         _Float16 *wrow = hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const half4 hv = { (_Float16)h[4 * q], (_Float16)h[4 * q + 1], (_Float16)h[4 * q + 2], (_Float16)h[4 * q + 3] };
+            const half4 hv = { (_Float16)h[2 * q].x, (_Float16)h[2 * q].y, (_Float16)h[2 * q + 1].x, (_Float16)h[2 * q + 1].y };
             *reinterpret_cast<half4 *>(wrow + 8 * q) = hv;
         }
         STAMP(5);
