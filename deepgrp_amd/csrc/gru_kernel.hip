@@ -217,6 +217,10 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 
     // Softmax + merge of step t's partial logits.  The 16x16 logit tile (window = 4*(lane>>4) + reg,
     // class = lane & 15) is split by accumulator register over the waves, one value per lane.
+    // placement of the wave's first register (reg = wave) never changes: keep it out of the step loop
+    const int pwi = 4 * (lane >> 4) + (wave & 3);
+    const int p_off = rowoff[pwi];
+    const int64_t p_row0 = row0s[pwi];
     auto finish_step = [&](int t) {
         for (int reg = wave; reg < 4; reg += NW) {
             const float *dp = dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
@@ -232,16 +236,17 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
                 val = e * __builtin_amdgcn_rcpf(row_allsum(e));
             }
             if (cls < C && wi < nvalid) {
+                const int off = reg == wave ? p_off : rowoff[wi];
+                const int64_t row0 = reg == wave ? p_row0 : row0s[wi];
                 if (MODE == 0) {
-                    const int off = rowoff[wi];
                     if (off >= 0) {
                         lds_atomic_max(obuf + (off + t) * C + cls, __float_as_uint(val));
                     } else {
-                        const int64_t row = row0s[wi] + t;
+                        const int64_t row = row0 + t;
                         if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
                     }
                 } else {
-                    p.out[(row0s[wi] + t) * C + cls] = val;
+                    p.out[(row0 + t) * C + cls] = val;
                 }
             }
         }

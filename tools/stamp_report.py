@@ -4,7 +4,7 @@ import sys
 import numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4, 16).astype(np.float64)
 T = 200
-names = ["top:xa,loads,r+dense issue", "finish_step(t-2)", "g chain+sig(r)", "z chain+r*g+tanh", "sig(z)+blend+publish", "(unused)", "barrier wait"]
+names = ["barrier->top", "xa,loads,r chain,dense issue", "finish_step(t-2)", "g chain+sig(r)", "z chain+r*g+tanh", "sig(z)+blend+publish", "barrier wait"]
 full = a[(a[:, 0, 8] > 0)]
 print("workgroups", len(full))
 seg = full[:, :, :7] / T
