@@ -221,35 +221,85 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     const int pwi = 4 * (lane >> 4) + (wave & 3);
     const int p_off = rowoff[pwi];
     const int64_t p_row0 = row0s[pwi];
-    auto finish_step = [&](int t) {
-        for (int reg = wave; reg < 4; reg += NW) {
-            const float *dp = dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
-            float sum = dp[0];
+    auto finish_reg = [&](int t, int reg) {
+        const float *dp = dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
+        float sum = dp[0];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) sum += dp[w * 64];
-            const int wi = 4 * (lane >> 4) + reg;
-            const float lg = cls < C ? sum + fbias : -INFINITY;
-            float val = lg;
-            if (MODE != 2) {                                  // attention: softmax happens in the second kernel
-                const float m = row_allmax(lg);
-                const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg - m));   // 0 for the padding lanes
-                val = e * __builtin_amdgcn_rcpf(row_allsum(e));
-            }
-            if (cls < C && wi < nvalid) {
-                const int off = reg == wave ? p_off : rowoff[wi];
-                const int64_t row0 = reg == wave ? p_row0 : row0s[wi];
-                if (MODE == 0) {
-                    if (off >= 0) {
-                        lds_atomic_max(obuf + (off + t) * C + cls, __float_as_uint(val));
-                    } else {
-                        const int64_t row = row0 + t;
-                        if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
-                    }
+        for (int w = 1; w < NW; ++w) sum += dp[w * 64];
+        const int wi = 4 * (lane >> 4) + reg;
+        const float lg = cls < C ? sum + fbias : -INFINITY;
+        float val = lg;
+        if (MODE != 2) {                                  // attention: softmax happens in the second kernel
+            const float m = row_allmax(lg);
+            const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg - m));   // 0 for the padding lanes
+            val = e * __builtin_amdgcn_rcpf(row_allsum(e));
+        }
+        if (cls < C && wi < nvalid) {
+            const int off = reg == wave ? p_off : rowoff[wi];
+            const int64_t row0 = reg == wave ? p_row0 : row0s[wi];
+            if (MODE == 0) {
+                if (off >= 0) {
+                    lds_atomic_max(obuf + (off + t) * C + cls, __float_as_uint(val));
                 } else {
-                    p.out[(row0 + t) * C + cls] = val;
+                    const int64_t row = row0 + t;
+                    if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
                 }
+            } else {
+                p.out[(row0 + t) * C + cls] = val;
             }
         }
+    };
+    auto finish_step = [&](int t) {
+        for (int reg = wave; reg < 4; reg += NW) finish_reg(t, reg);
+    };
+    // The wave's first register again, cut into single-instruction stages that the step loop drops into the
+    // gaps of the r chain (a wave issues in order and waits for the matrix pipe at every back-to-back MFMA, so
+    // what sits between two MFMAs in program order is nearly free).  Used up to 128 units; beyond, the
+    // z-streaming variant has no registers to spare.
+    constexpr bool STAGED = NW <= 4;
+    const bool pr_on = cls < C && pwi < nvalid;
+    float fs_d[NW], fs_lg = 0.0f, fs_m = 0.0f, fs_e = 0.0f, fs_s = 0.0f;
+    constexpr int FS_STAGES = 12;
+    auto finish_stage = [&](int st, int t) {
+        switch (st) {
+        case 0: {
+            const float *dp = dpart + ((size_t)(t & 1) * 4 + (wave & 3)) * NW * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) fs_d[w] = dp[w * 64];
+        } break;
+        case 1: {
+            float sum = fs_d[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sum += fs_d[w];
+            fs_lg = cls < C ? sum + fbias : -INFINITY;
+        } break;
+        case 2: if (MODE != 2) fs_m = row_max_ror<8>(fs_lg); break;
+        case 3: if (MODE != 2) fs_m = row_max_ror<4>(fs_m); break;
+        case 4: if (MODE != 2) fs_m = row_max_ror<2>(fs_m); break;
+        case 5: if (MODE != 2) fs_m = row_max_ror<1>(fs_m); break;
+        case 6: if (MODE != 2) fs_e = __builtin_amdgcn_exp2f(1.4426950408889634f * (fs_lg - fs_m)); break;
+        case 7: if (MODE != 2) fs_s = fs_e + row_ror<8>(fs_e); break;
+        case 8: if (MODE != 2) fs_s += row_ror<4>(fs_s); break;
+        case 9: if (MODE != 2) fs_s += row_ror<2>(fs_s); break;
+        case 10: if (MODE != 2) fs_s += row_ror<1>(fs_s); break;
+        default: if (MODE != 2) fs_e *= __builtin_amdgcn_rcpf(fs_s); break;
+        }
+    };
+    auto finish_commit = [&](int t) {
+        const float val = MODE == 2 ? fs_lg : fs_e;
+        if (pr_on) {
+            if (MODE == 0) {
+                if (p_off >= 0) {
+                    lds_atomic_max(obuf + (p_off + t) * C + cls, __float_as_uint(val));
+                } else {
+                    const int64_t row = p_row0 + t;
+                    if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
+                }
+            } else {
+                p.out[(p_row0 + t) * C + cls] = val;
+            }
+        }
+        for (int reg = wave + NW; reg < 4; reg += NW) finish_reg(t, reg);      // NW < 4: the wave's other registers
     };
     // Dense on this wave's 32 units of the hidden tile `hb`: rows r (window) and r+16 (its rc) accumulate
     // (= the Average; the attention pre-pass also stores it, step tt); issue only -- the partial logits are stored by dense_store once the MFMAs are done.
@@ -298,13 +348,25 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 #pragma unroll
         for (int k = 0; k < KS; ++k) af[k] = *reinterpret_cast<const half8 *>(arow + 16 * k);
         f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
+        if (STAGED) finish_stage(0, t);                      // (steps 0 and 1 run the stages on stale data, uncommitted)
 #pragma unroll
-        for (int k = 0; k < KS; ++k) ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], af[k], ar, 0, 0, 0);
+        for (int k = 0; k < KS; ++k) {
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], af[k], ar, 0, 0, 0);
+            if (STAGED) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int st = 1 + k * (FS_STAGES - 1) / KS; st < 1 + (k + 1) * (FS_STAGES - 1) / KS; ++st) finish_stage(st, t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         f32x4 dpl = zero4;
         if (t > 0) dpl = dense_issue(hcur, t - 1);
         if (PIPE) __builtin_amdgcn_sched_barrier(0);
         STAMP(1);
-        if (t > 1) finish_step(t - 2);
+        if (t > 1) {
+            if (STAGED) finish_commit(t - 2);
+            else finish_step(t - 2);
+        }
         if (PIPE) __builtin_amdgcn_sched_barrier(0);
         STAMP(2);
         f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[KS], xa, zero16, 0, 0, 0);
