@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -91,6 +92,31 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     m->nfrag = 3 * (m->KS + 1) + 3;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr;
     const int KS = m->KS, NF = m->nfrag, u3 = 3 * u;
+    // The update z*h + (1-z)*tanh(g) can be written with ONE reciprocal, of (1 + 2^az)(1 + 2^ag), if that
+    // product cannot overflow: |h| <= 1 and 0 < r < 1 bound both pre-activations by the weights' absolute
+    // column sums.  Checked here once; models that fail it (or DGRP_GRU_SAFE=1) take the two-reciprocal kernel.
+    {
+        double worst = 0.0;
+        for (int j = 0; j < u; ++j) {
+            double bz = 1.0, bg = 0.0;                                        // 1.0: the z gate's "+1" fold (below)
+            double kz = 0.0, kg = 0.0;
+            for (int c = 0; c < 5; ++c) {
+                kz = std::max(kz, (double)fabsf(kernel[(size_t)c * u3 + j]));
+                kg = std::max(kg, (double)fabsf(kernel[(size_t)c * u3 + 2 * u + j]));
+            }
+            double sz = kz + fabs((double)bias[j] + (double)bias[u3 + j]);
+            double sg = kg + fabsf(bias[2 * u + j]) + fabsf(bias[u3 + 2 * u + j]);
+            for (int k = 0; k < u; ++k) {
+                sz += fabsf(rec[(size_t)k * u3 + j]);
+                sg += fabsf(rec[(size_t)k * u3 + 2 * u + j]);
+            }
+            bz += 1.4426950408889634 * sz;
+            bg += 2.8853900817779268 * sg;
+            if (!(bz + bg <= worst)) worst = bz + bg;                         // NaN weights -> not provable
+        }
+        const char *safe = getenv("DGRP_GRU_SAFE");
+        m->onercp = (m->NW <= 4 && worst <= 120.0 && !(safe && safe[0] == '1')) ? 1 : 0;
+    }
 
     std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
     auto at = [&](int w, int f, int l, int j) -> uint16_t & { return pack[(((size_t)w * NF + f) * 64 + l) * 8 + j]; };
@@ -119,6 +145,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
                                                    : bias[u3 + 2 * u + unit];
                     }
                     v *= gs;
+                    if (m->onercp && g == 0 && j == 5 && uok) v += 1.0f;        // one-reciprocal blend wants 2 * 2^az
                     const uint16_t hi = f2h(v);
                     at(w, g * (KS + 1) + KS, l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
                 }
@@ -263,6 +290,12 @@ DGRP_EXPORT int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int
     if (C) *C = m->C;
     if (attention) *attention = m->attention;
     return DGRP_OK;
+}
+
+DGRP_EXPORT int dgrp_model_flags(const dgrp_model *m)
+{
+    DGRP_REQUIRE(m, "dgrp_model_flags: NULL model");
+    return m->onercp ? 1 : 0;
 }
 
 // attention keeps avg[t] (fp16 [nw,T,UP]) and the avg half of the logits (fp32 [nw,T,C]) between kernels

@@ -6,6 +6,7 @@
 struct dgrp_model {
     int T, u, C, attention;
     int cell;    // 0 = GRU (reset_after), 1 = LSTM
+    int onercp;  // GRU, u <= 128: pre-activations provably small enough for the one-reciprocal blend (gru_kernel.hip)
     int UP;      // units padded to a multiple of 32
     int NW;      // waves per workgroup = UP / 32, one 32-unit column slice of every gate per wave
     int KS;      // 16-deep k-steps of the recurrent contraction = UP / 16

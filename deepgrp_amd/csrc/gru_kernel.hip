@@ -121,7 +121,7 @@ __host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 
 #ifndef DGRP_PIPE
 #define DGRP_PIPE 1
 #endif
-template <int NW, int MODE>
+template <int NW, int MODE, bool ONERCP>
 __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params p)
 {
     constexpr bool PIPE = DGRP_PIPE;
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 
     f32x2 h[8];                         // fp32 master state, pairs of adjacent units (packed VALU operands)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = f32x2{ 0.0f, 0.0f };
+    for (int i = 0; i < 8; ++i) h[i] = ONERCP ? f32x2{ -1.0f, -1.0f } : f32x2{ 0.0f, 0.0f };   // ONERCP keeps h - 1
 
     _Float16 *hcur = hbuf, *hnxt = hbuf + 32 * HS;
     const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -402,7 +402,8 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             } else {
 #pragma unroll
                 for (int i = 2 * ((k - KH) * 8 / (KS - KH)); i < 2 * ((k - KH + 1) * 8 / (KS - KH)); i += 2) {
-                    hh[i / 2] = 1.0f - 2.0f * rcp1p_exp2_pair(ag[i], ag[i + 1]);
+                    if (ONERCP) hh[i / 2] = f32x2{ __builtin_amdgcn_exp2f(ag[i]), __builtin_amdgcn_exp2f(ag[i + 1]) } + 1.0f;   // A = 1 + 2^ag
+                    else hh[i / 2] = 1.0f - 2.0f * rcp1p_exp2_pair(ag[i], ag[i + 1]);
                 }
             }
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
@@ -411,15 +412,26 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         STAMP(4);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const f32x2 z = rcp1p_exp2_pair(az[2 * i], az[2 * i + 1]);
-            h[i] = hh[i] + z * (h[i] - hh[i]);                                 // z*h + (1-z)*hh
+            if (ONERCP) {
+                // h' - 1 = [ (h - 1)(1 + Eg) - 2 Ez ] / [ (1 + Eg)(1 + Ez) ],  Eg = 2^ag (tanh), Ez = 2^az (sigmoid):
+                // one reciprocal for both gates; the packed z bias carries +1, so the exponential below is 2 Ez.
+                // The model constructor proved (1 + Eg)(1 + Ez) finite (api.hip).
+                const f32x2 e2 = { __builtin_amdgcn_exp2f(az[2 * i]), __builtin_amdgcn_exp2f(az[2 * i + 1]) };
+                const f32x2 d = hh[i] * (0.5f * e2 + 1.0f);
+                const f32x2 n = h[i] * hh[i] - e2;
+                h[i] = n * f32x2{ __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y) };
+            } else {
+                const f32x2 z = rcp1p_exp2_pair(az[2 * i], az[2 * i + 1]);
+                h[i] = hh[i] + z * (h[i] - hh[i]);                             // z*h + (1-z)*hh
+            }
         }
         // ---- publish h_t (fp16) for the next step's B operand: a lane holds 4 x 4 consecutive units of
         // one row (transposed tile), i.e. four 8-byte stores
         _Float16 *wrow = hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const half4 hv = { (_Float16)h[2 * q].x, (_Float16)h[2 * q].y, (_Float16)h[2 * q + 1].x, (_Float16)h[2 * q + 1].y };
+            const f32x2 h0 = ONERCP ? h[2 * q] + 1.0f : h[2 * q], h1 = ONERCP ? h[2 * q + 1] + 1.0f : h[2 * q + 1];
+            const half4 hv = { (_Float16)h0.x, (_Float16)h0.y, (_Float16)h1.x, (_Float16)h1.y };
             *reinterpret_cast<half4 *>(wrow + 8 * q) = hv;
         }
         STAMP(5);
@@ -752,26 +764,35 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
 }
 
 // ------------------------------------------------------------------------------------------
-template <int NW, int MODE>
+template <int NW, int MODE, bool ONERCP>
 static int launch_gru_mode(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
     static bool configured = false;          // per instantiation; the attribute is per function, not per launch
     if (!configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_fused_kernel<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_fused_kernel<NW, MODE, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
-    hipLaunchKernelGGL((gru_fused_kernel<NW, MODE>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+    hipLaunchKernelGGL((gru_fused_kernel<NW, MODE, ONERCP>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
 }
 
 template <int NW>
-static int launch_gru(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
+static int launch_gru(const gru_params &p, int64_t groups, size_t lds, bool onercp, hipStream_t stream)
 {
+    if constexpr (NW <= 4) {
+        if (onercp) {
+            switch (p.mode) {
+            case 0: return launch_gru_mode<NW, 0, true>(p, groups, lds, stream);
+            case 1: return launch_gru_mode<NW, 1, true>(p, groups, lds, stream);
+            default: return launch_gru_mode<NW, 2, true>(p, groups, lds, stream);
+            }
+        }
+    }
     switch (p.mode) {
-    case 0: return launch_gru_mode<NW, 0>(p, groups, lds, stream);
-    case 1: return launch_gru_mode<NW, 1>(p, groups, lds, stream);
-    default: return launch_gru_mode<NW, 2>(p, groups, lds, stream);
+    case 0: return launch_gru_mode<NW, 0, false>(p, groups, lds, stream);
+    case 1: return launch_gru_mode<NW, 1, false>(p, groups, lds, stream);
+    default: return launch_gru_mode<NW, 2, false>(p, groups, lds, stream);
     }
 }
 
@@ -839,7 +860,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     }
 #ifdef DGRP_STAMP
     if (p.stamps && m->NW == 4) {
-        int rc = launch_gru<4>(p, groups, lds, stream);
+        int rc = launch_gru<4>(p, groups, lds, m->onercp != 0, stream);
         (void)hipStreamSynchronize(stream);
         std::vector<uint64_t> hst(stamp_bytes / 8);
         (void)hipMemcpy(hst.data(), p.stamps, stamp_bytes, hipMemcpyDeviceToHost);
@@ -849,14 +870,14 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     }
 #endif
     switch (m->NW) {
-    case 1: return launch_gru<1>(p, groups, lds, stream);
-    case 2: return launch_gru<2>(p, groups, lds, stream);
-    case 3: return launch_gru<3>(p, groups, lds, stream);
-    case 4: return launch_gru<4>(p, groups, lds, stream);
-    case 5: return launch_gru<5>(p, groups, lds, stream);
-    case 6: return launch_gru<6>(p, groups, lds, stream);
-    case 7: return launch_gru<7>(p, groups, lds, stream);
-    case 8: return launch_gru<8>(p, groups, lds, stream);
+    case 1: return launch_gru<1>(p, groups, lds, m->onercp != 0, stream);
+    case 2: return launch_gru<2>(p, groups, lds, m->onercp != 0, stream);
+    case 3: return launch_gru<3>(p, groups, lds, m->onercp != 0, stream);
+    case 4: return launch_gru<4>(p, groups, lds, m->onercp != 0, stream);
+    case 5: return launch_gru<5>(p, groups, lds, m->onercp != 0, stream);
+    case 6: return launch_gru<6>(p, groups, lds, m->onercp != 0, stream);
+    case 7: return launch_gru<7>(p, groups, lds, m->onercp != 0, stream);
+    case 8: return launch_gru<8>(p, groups, lds, m->onercp != 0, stream);
     default:
         dgrp_set_error("units=%d not supported by the GRU kernel (max 256)", m->u);
         return DGRP_EINVAL;

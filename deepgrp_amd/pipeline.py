@@ -91,6 +91,11 @@ class DeviceModel:
     input_shape = property(lambda self: (None, self.vecsize, 5))
     output_shape = property(lambda self: (None, self.vecsize, self.classes))
 
+    @property
+    def kernel_flags(self) -> int:
+        """dgrp_model_flags: bit 0 = the one-reciprocal GRU blend was provably safe for these weights."""
+        return int(lib().dgrp_model_flags(self.handle))
+
     def close(self):
         if getattr(self, "handle", None):
             lib().dgrp_model_destroy(self.handle)

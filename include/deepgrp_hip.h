@@ -103,6 +103,11 @@ int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, const float *h
                            const float *h_ff_bias);
 int dgrp_model_destroy(dgrp_model *m);
 int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int *attention);
+/* Which kernel variant the constructor chose (diagnostic; results are the same within tolerance):
+ * bit 0 = GRU blend with one reciprocal per (row, unit) -- only when the weights' absolute column sums
+ * prove (1 + 2^az)(1 + 2^ag) finite in float32; otherwise (or with DGRP_GRU_SAFE=1 in the environment at
+ * construction) the two-reciprocal form.  Negative on a NULL model. */
+int dgrp_model_flags(const dgrp_model *m);
 
 /* ---- A4: model.predict_on_batch (deepgrp/prediction.py:106)
  * Bytes of scratch HBM dgrp_forward_* needs for `nw` windows in one call. */

@@ -144,6 +144,43 @@ def test_forward_windows_vs_oracle(dev, orc, u, T, attention, gain, s, nw):
     dm.close()
 
 
+@pytest.mark.parametrize("u,T,attention", [(128, 200, False), (96, 40, True), (32, 30, False)])
+def test_gru_blend_variants_agree(dev, orc, u, T, attention, monkeypatch):
+    """The constructor picks the one-reciprocal blend when the weights' column sums prove it cannot
+    overflow (dgrp_model_flags bit 0); DGRP_GRU_SAFE=1 forces the two-reciprocal kernel.  Both must be
+    within tolerance of the float64 statement, and of each other far closer than that."""
+    rng = np.random.default_rng(u + T)
+    s, nw = 11, 37
+    idx = _seq_idx(rng, (nw + 2) * s + T)
+    w, fast = _model(orc, u, T, attention, 1.0)
+    assert fast.kernel_flags & 1
+    monkeypatch.setenv("DGRP_GRU_SAFE", "1")
+    _, safe = _model(orc, u, T, attention, 1.0)
+    monkeypatch.delenv("DGRP_GRU_SAFE")
+    assert not (safe.kernel_flags & 1)
+    want = orc.nn_forward(idx, w, s, 0, nw, np.float64)
+    a = fast.forward_windows(_t(idx, dev), s, 0, nw).cpu().numpy()
+    b = safe.forward_windows(_t(idx, dev), s, 0, nw).cpu().numpy()
+    print(f"u={u}: fast {np.abs(a - want).max():.2e} safe {np.abs(b - want).max():.2e} fast-safe {np.abs(a - b).max():.2e}")
+    assert np.abs(a - want).max() < 1e-3 and np.abs(b - want).max() < 1e-3
+    assert np.abs(a - b).max() < 2e-4
+    fast.close(); safe.close()
+
+
+def test_gru_large_weights_take_the_safe_blend(dev, orc):
+    """Weights whose pre-activations could reach 2^60 and beyond: the overflow bound fails, the two-reciprocal
+    kernel runs, and the probabilities stay finite and on the float64 statement (saturated gates)."""
+    rng = np.random.default_rng(5)
+    u, T, s, nw = 128, 60, 13, 29
+    w, dm = _model(orc, u, T, False, 12.0)
+    assert not (dm.kernel_flags & 1)
+    idx = _seq_idx(rng, (nw + 2) * s + T)
+    got = dm.forward_windows(_t(idx, dev), s, 0, nw).cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got.sum(axis=2), 1.0, atol=1e-5)
+    dm.close()
+
+
 @pytest.mark.parametrize("u,T,gain,s,nw", [(16, 30, 1.0, 4, 21), (64, 50, 1.5, 7, 40), (96, 40, 1.0, 9, 17),
                                            (128, 200, 1.0, 50, 35), (128, 60, 2.0, 25, 33), (100, 25, 1.0, 3, 19)])
 def test_lstm_forward_vs_oracle(dev, orc, u, T, gain, s, nw):
