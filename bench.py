@@ -161,7 +161,7 @@ def main():
                        "rows_out": int(nrows), "parallelism": f"contig-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "gru_fused_kernel<4,0>", "flop_per_window": FLOP_PER_WINDOW, "avg_launch_ms": round(avg_ms, 3),
+                         "kernel": "gru_fused_kernel<4, 0, %s>" % ("true" if model.kernel_flags & 1 else "false"), "flop_per_window": FLOP_PER_WINDOW, "avg_launch_ms": round(avg_ms, 3),
                          "windows_per_launch": int(np.mean(kern_windows)), "launches_timed": len(kern_ms)},
         }
         if not args.no_cpu_baseline:

@@ -1,0 +1,44 @@
+"""Turn the rocprofv3 output directories of tools/_prof.sh (kernel stats + one FETCH_SIZE and one WRITE_SIZE
+pass) into the committed summaries under profiles/:  python tools/summarize_profiles.py gpurun_out r01"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+
+stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))[0]
+with open(stats) as f, open(os.path.join(out, f"{tag}_bench50mbp_kernel_stats.csv"), "w") as g:
+    g.write(f.read())
+
+rows = []
+agg = {}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    path = glob.glob(os.path.join(src, "prof_" + counter.split("_")[0].lower(), "*", "*_counter_collection.csv"))[0]
+    acc = defaultdict(list)
+    meta = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            meta[r["Kernel_Name"]] = (r["VGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"])
+    for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
+        rows.append((counter, k, len(v), round(sum(v) / len(v), 3)) + meta[k])
+        if "gru_fused_kernel" in k:
+            agg[counter] = sum(v) / len(v)
+            agg["kernel"] = k.replace("void ", "").replace("(gru_params)", "")
+with open(os.path.join(out, f"{tag}_bench50mbp_pmc_summary.csv"), "w", newline="") as g:
+    w = csv.writer(g)
+    w.writerow(["counter", "kernel", "dispatches", "avg_value_KB", "vgpr", "lds_bytes", "workgroup"])
+    w.writerows(rows)
+
+windows = 999596
+hbm = (2 * agg["FETCH_SIZE"] + agg["WRITE_SIZE"]) * 1024
+json.dump({
+    "kernel": agg["kernel"], "windows_per_launch": windows,
+    "FETCH_SIZE_KB": agg["FETCH_SIZE"], "WRITE_SIZE_KB": agg["WRITE_SIZE"],
+    "hbm_bytes_per_launch": hbm, "hbm_bytes_per_window": hbm / windows,
+    "correction": "gfx950: FETCH_SIZE counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md, HBM section) -> 2*FETCH_SIZE + WRITE_SIZE, KB*1024",
+    "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --mbp 50 --steps 1 --warmup 0 --no-cpu-baseline (separate passes)",
+}, open(os.path.join(out, f"{tag}_gru_traffic.json"), "w"), indent=1)
+print(open(os.path.join(out, f"{tag}_gru_traffic.json")).read())
