@@ -46,6 +46,8 @@ _SIGNATURES = {
     "dgrp_mss_segments_host": (cint, [vp, i64, vp, i64, C.POINTER(i64)]),
     "dgrp_segments_workspace_bytes": (i64, [i64]),
     "dgrp_segments": (cint, [vp, i64, i64, i32, vp, i64, vp, vp, i64, vp]),
+    "dgrp_confusion_matrix": (cint, [vp, vp, i64, cint, vp, vp, vp]),
+    "dgrp_filter_segments": (cint, [vp, vp, i64, i64, vp]),
 }
 
 _lib = None

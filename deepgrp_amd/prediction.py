@@ -1,5 +1,6 @@
-"""deepgrp_amd.prediction -- mirror of deepgrp/prediction.py:14-111 (the four functions on the
-`deepgrp predict` path) over the HIP kernels.
+"""deepgrp_amd.prediction -- mirror of deepgrp/prediction.py over the HIP kernels: the four functions on the
+`deepgrp predict` path (:14-111) and the evaluation surface next to it (predict_complete :114-141, metrics
+:144-241, filter_segments :244-260).
 
 `fetch_validation_batch` returns a WindowDataset instead of a tf.data.Dataset: iterating it
 yields the same float32 [<=B, T, 5] batches; handing it to `predict` together with a model from
@@ -7,7 +8,8 @@ deepgrp_amd.model.load_model takes the fused device path (no window is ever mate
 Any other (model, iterable) pair runs the reference's generic loop."""
 from __future__ import annotations
 
-from typing import Iterable, Iterator, Tuple
+import os
+from typing import Dict, Iterable, Iterator, Tuple, Union
 
 import numpy as np
 import torch
@@ -128,3 +130,159 @@ def softmax(array: np.ndarray) -> np.ndarray:
     check(lib().dgrp_softmax_labels(d_p.data_ptr(), n, c, d_sm.data_ptr(), d_l.data_ptr(), work.data_ptr(), 4096,
                                     stream_ptr()), "dgrp_softmax_labels")
     return d_sm.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+# N2: predict_complete and the evaluation helpers (prediction.py:68-86, :114-260)
+# ------------------------------------------------------------------------------------------------
+def setup_prediction_from_options_checkpoint(options: Options, logdir) -> DeviceModel:
+    """prediction.py:68-86 restores the latest TensorFlow checkpoint under `logdir` into a freshly created
+    model.  TensorFlow's checkpoint bundles are not readable here; the weights are taken from a Keras HDF5 file
+    instead: `logdir` is either that file or a directory holding one (`*.h5` / `*.hdf5`, the newest wins).
+    The file's layer graph must agree with `options` (vecsize, units, attention, rnn)."""
+    from .model import ModelFormatError, load_model
+    path = os.fspath(logdir)
+    if os.path.isdir(path):
+        cands = [os.path.join(path, f) for f in os.listdir(path) if f.endswith((".h5", ".hdf5"))]
+        if not cands:
+            raise ModelFormatError(f"{path}: no Keras HDF5 model (*.h5, *.hdf5) found; TensorFlow checkpoint "
+                                   "bundles cannot be read without TensorFlow -- export the model with model.save()")
+        path = max(cands, key=os.path.getmtime)
+    model = load_model(path, custom_objects={"ReverseComplement": None})
+    for name, have in (("vecsize", model.vecsize), ("units", model.units), ("attention", bool(model.attention))):
+        want = options[name]
+        if (bool(want) if name == "attention" else int(want)) != have:
+            raise ModelFormatError(f"{path}: {name}={have} in the file but {want} in the options")
+    return model
+
+
+def predict_complete(step_size: int, options: Options, logdir, data, use_mss: bool = False) -> np.ndarray:
+    """Restores a model and predicts for a sequence (prediction.py:114-141): `data` has `.fwd` (one-hot
+    [5, N]) and `.truelbl` ([C, N]); returns apply_mss's one-hot labels or the softmax of the merged
+    probabilities."""
+    model = setup_prediction_from_options_checkpoint(options, logdir)
+    val_iterator = fetch_validation_batch(data.fwd, step_size, options.batch_size, options.vecsize)
+    output_shape = data.truelbl.shape[::-1]
+    predictions = predict(model, val_iterator, output_shape, step_size)
+    if use_mss:
+        return apply_mss(predictions, options)
+    return softmax(predictions)
+
+
+def calculate_multiclass_matthews_cc(cnf_matrix: np.ndarray) -> float:
+    """R_K / multi-class Matthews correlation coefficient of a confusion matrix (prediction.py:144-162)."""
+    cnf_matrix = np.asarray(cnf_matrix)
+    t_sum = cnf_matrix.sum(axis=1, dtype=float)
+    p_sum = cnf_matrix.sum(axis=0, dtype=float)
+    n_correct = np.trace(cnf_matrix, dtype=float)
+    n_samples = p_sum.sum()
+    cov_ytyp = n_correct * n_samples - np.dot(t_sum, p_sum)
+    cov_ypyp = n_samples**2 - np.dot(p_sum, p_sum)
+    cov_ytyt = n_samples**2 - np.dot(t_sum, t_sum)
+    return cov_ytyp / np.sqrt(cov_ytyt * cov_ypyp)
+
+
+def _calculate_metrics(cnf_matrix: np.ndarray) -> Dict[str, Union[np.ndarray, float]]:
+    """Per-class rates from a confusion matrix, same keys and formulas as prediction.py:165-201."""
+    cnf_matrix = np.asarray(cnf_matrix)
+    tp = np.diag(cnf_matrix).astype(float)
+    fp = (cnf_matrix.sum(axis=0) - tp).astype(float)
+    fn = (cnf_matrix.sum(axis=1) - tp).astype(float)
+    tn = (cnf_matrix.sum() - (fp + fn + tp)).astype(float)
+    metrics: Dict[str, Union[np.ndarray, float]] = {}
+    metrics["TPR"] = tp / (tp + fn)
+    metrics["TNR"] = tn / (tn + fp)
+    metrics["PPV"] = tp / (tp + fp)
+    metrics["NPV"] = tn / (tn + fn)
+    metrics["FPR"] = fp / (fp + tn)
+    metrics["FNR"] = fn / (tp + fn)
+    metrics["FDR"] = fp / (tp + fp)
+    metrics["ACC"] = (tp + tn) / (tp + fp + fn + tn)
+    metrics["F1"] = 2 * metrics["TPR"] * metrics["PPV"] / (metrics["TPR"] + metrics["PPV"])
+    metrics["MCC"] = calculate_multiclass_matthews_cc(cnf_matrix)
+    return metrics
+
+
+def _device_labels(a) -> "torch.Tensor | None":
+    """int8 device copy of a label array when it can go through the kernels (values within int8), else None."""
+    if isinstance(a, torch.Tensor):
+        if a.is_cuda and a.dtype == torch.int8 and a.dim() == 1:
+            return a.contiguous()
+        a = a.cpu().numpy()
+    a = np.asarray(a)
+    if a.ndim != 1 or a.size == 0 or a.dtype.kind not in "iu":
+        return None
+    if a.min() < -128 or a.max() > 127:
+        return None
+    return torch.from_numpy(np.ascontiguousarray(a.astype(np.int8))).to(require_gpu())
+
+
+def confusion_matrix(truelbl, predictedlbl) -> np.ndarray:
+    """Confusion matrix from integer label arrays (prediction.py:204-222); numpy arrays or int8 CUDA tensors.
+    n_classes = (max over both) - (min over both) + 1 and the cells are indexed with the raw labels, exactly as
+    the reference does; label sets it cannot index raise IndexError there and here."""
+    t_size = truelbl.numel() if isinstance(truelbl, torch.Tensor) else np.asarray(truelbl).size
+    p_size = predictedlbl.numel() if isinstance(predictedlbl, torch.Tensor) else np.asarray(predictedlbl).size
+    assert t_size == p_size
+    d_t, d_p = _device_labels(truelbl), _device_labels(predictedlbl)
+    if d_t is None or d_p is None:
+        raise TypeError("confusion_matrix needs one-dimensional, non-empty integer label arrays within int8 range")
+    lo = min(int(d_t.min()), int(d_p.min()))
+    hi = max(int(d_t.max()), int(d_p.max()))
+    k = hi - lo + 1
+    if lo < -k or hi >= k:
+        raise IndexError(f"index {hi if hi >= k else lo} is out of bounds for axis 0 with size {k}")
+    if k > 16:
+        raise ValueError("confusion_matrix: more than 16 classes are not supported on the device")
+    if lo < 0:                                              # numpy wraps negative indices
+        d_t = torch.where(d_t < 0, d_t + k, d_t)
+        d_p = torch.where(d_p < 0, d_p + k, d_p)
+    d_cnf = torch.empty((k, k), dtype=torch.int64, device=d_t.device)
+    d_bad = torch.empty(1, dtype=torch.int32, device=d_t.device)
+    check(lib().dgrp_confusion_matrix(d_t.data_ptr(), d_p.data_ptr(), d_t.numel(), k, d_cnf.data_ptr(), d_bad.data_ptr(),
+                                      stream_ptr()), "dgrp_confusion_matrix")
+    assert int(d_bad.item()) == 0
+    return d_cnf.cpu().numpy().astype(int)
+
+
+def calculate_metrics(predictions_class, true_class) -> Tuple[np.ndarray, Dict[str, Union[np.ndarray, float]]]:
+    """Confusion matrix and the metrics dictionary incl. TotalACC (prediction.py:225-241)."""
+    cnf_matrix = confusion_matrix(true_class, predictions_class)
+    n = true_class.numel() if isinstance(true_class, torch.Tensor) else np.asarray(true_class).shape[0]
+    if isinstance(true_class, torch.Tensor) or isinstance(predictions_class, torch.Tensor):
+        a, b = _device_labels(true_class), _device_labels(predictions_class)
+        overall_acc = int((a == b).sum()) / n
+    else:
+        overall_acc = (np.asarray(true_class) == np.asarray(predictions_class)).sum() / n
+    metrics = _calculate_metrics(cnf_matrix)
+    metrics["TotalACC"] = overall_acc
+    return cnf_matrix, metrics
+
+
+def filter_segments(array, min_len: int = 50) -> None:
+    """Clear runs of one positive label shorter than `min_len`, in place (prediction.py:244-260).  Accepts a
+    numpy array (any dtype whose values fit int8; written back in place) or an int8 CUDA tensor."""
+    if isinstance(array, torch.Tensor) and array.is_cuda:
+        if array.dtype != torch.int8 or array.dim() != 1 or not array.is_contiguous():
+            raise TypeError("device labels must be a contiguous one-dimensional int8 tensor")
+        check(lib().dgrp_filter_segments(array.data_ptr(), array.data_ptr(), array.numel(), int(min_len), stream_ptr()),
+              "dgrp_filter_segments")
+        return
+    a = np.asarray(array)
+    if a.ndim != 1:
+        raise ValueError("filter_segments works on one-dimensional label arrays")
+    if a.size == 0:
+        return
+    vals = a if a.dtype.kind in "iu" else None
+    if vals is None:
+        if not np.all(a == np.round(a)):
+            raise TypeError("filter_segments needs integer-valued labels")
+    if a.min() < -128 or a.max() > 127:
+        raise ValueError("labels outside the int8 range are not supported on the device")
+    dev = require_gpu()
+    d = torch.from_numpy(np.ascontiguousarray(a.astype(np.int8))).to(dev)
+    out = torch.empty_like(d)
+    check(lib().dgrp_filter_segments(d.data_ptr(), out.data_ptr(), d.numel(), int(min_len), stream_ptr()),
+          "dgrp_filter_segments")
+    keep = out.cpu().numpy() != 0
+    array[~keep & (a > 0)] = 0

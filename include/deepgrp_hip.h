@@ -166,6 +166,16 @@ int dgrp_segments(const int8_t *d_labels, int64_t n, int64_t offset, int32_t con
                   dgrp_segment *d_records, int64_t cap, int64_t *d_count, void *d_work,
                   int64_t work_bytes, void *stream);
 
+/* ---- N2: evaluation helpers of deepgrp.prediction on label arrays that are already in HBM.
+ * deepgrp.prediction.confusion_matrix (deepgrp/prediction.py:204-222): d_cnf int64 [ncls, ncls] (zeroed here),
+ * cnf[true, pred] += 1 per base; labels int8 in [0, ncls), ncls <= 16, arrays 16-byte aligned.  *d_bad (device
+ * int) is set to 1 if any label falls outside [0, ncls) -- the reference raises IndexError there. */
+int dgrp_confusion_matrix(const int8_t *d_true, const int8_t *d_pred, int64_t n, int ncls, int64_t *d_cnf,
+                          int *d_bad, void *stream);
+/* deepgrp.prediction.filter_segments (deepgrp/prediction.py:244-260): runs of one positive label shorter than
+ * min_len become 0.  d_out may be d_labels (the reference works in place). */
+int dgrp_filter_segments(const int8_t *d_labels, int8_t *d_out, int64_t n, int64_t min_len, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

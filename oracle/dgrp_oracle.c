@@ -419,6 +419,52 @@ ORC_API int64_t orc_segments(const int64_t *classes, int64_t size, int64_t offse
 }
 
 /* ------------------------------------------------------------------------- */
+/* N2  evaluation helpers next to the path: deepgrp/prediction.py:204-260      */
+/* ------------------------------------------------------------------------- */
+/* confusion_matrix (prediction.py:204-222): n_classes = max over both arrays - min over both + 1, a zero
+ * int matrix, then cnf[t, p] += 1 element by element -- indexed with the RAW labels (the minimum is not
+ * subtracted), so a label outside [-n_classes, n_classes) raises IndexError in numpy and a negative one wraps.
+ * Returns n_classes, or -1 where numpy would raise.  cnf must hold n_classes^2 entries (call with cnf == NULL
+ * to get n_classes first). */
+ORC_API int64_t orc_confusion_matrix(const int64_t *truelbl, const int64_t *predlbl, int64_t n, int64_t *cnf)
+{
+    if (n <= 0) return -1;                                   /* max() of an empty array raises */
+    int64_t lo = truelbl[0], hi = truelbl[0];
+    for (int64_t i = 0; i < n; ++i) {
+        if (truelbl[i] < lo) lo = truelbl[i];
+        if (truelbl[i] > hi) hi = truelbl[i];
+        if (predlbl[i] < lo) lo = predlbl[i];
+        if (predlbl[i] > hi) hi = predlbl[i];
+    }
+    const int64_t k = hi - lo + 1;
+    if (!cnf) return k;
+    for (int64_t i = 0; i < k * k; ++i) cnf[i] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t t = truelbl[i], q = predlbl[i];
+        if (t < -k || t >= k || q < -k || q >= k) return -1;
+        if (t < 0) t += k;
+        if (q < 0) q += k;
+        cnf[t * k + q] += 1;
+    }
+    return k;
+}
+
+/* filter_segments (prediction.py:244-260), in place: walk the positive positions; a run of equal labels that
+ * starts at one of them and is shorter than min_len is zeroed. */
+ORC_API void orc_filter_segments(int64_t *array, int64_t n, int64_t min_len)
+{
+    int64_t next_idx = 0;
+    for (int64_t idx = 0; idx < n; ++idx) {
+        if (!(array[idx] > 0) || next_idx > idx) continue;
+        next_idx = idx + 1;
+        int64_t found = 1;
+        while (next_idx < n && array[next_idx] == array[idx]) { ++found; ++next_idx; }
+        if (found < min_len)
+            for (int64_t k = idx; k < next_idx; ++k) array[k] = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* A4  model forward: deepgrp/model.py:293-336 (graph), Keras 2.5 layer math  */
 /* ------------------------------------------------------------------------- */
 /*

@@ -77,6 +77,10 @@ def lib() -> C.CDLL:
         f = getattr(L, name)
         f.restype = C.c_int
         f.argtypes = [vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.orc_confusion_matrix.restype = i64
+    L.orc_confusion_matrix.argtypes = [vp, vp, i64, vp]
+    L.orc_filter_segments.restype = None
+    L.orc_filter_segments.argtypes = [vp, i64, i64]
     L.orc_max_threads.restype = C.c_int
     _LIB = L
     return L
@@ -228,6 +232,28 @@ def segments(classes: np.ndarray, offset: int) -> np.ndarray:
     if n:
         lib().orc_segments(_p(classes), classes.size, offset, _p(rec))
     return rec
+
+
+# --------------------------------------------------------------------------- N2
+def confusion_matrix(truelbl: np.ndarray, predictedlbl: np.ndarray) -> np.ndarray:
+    """deepgrp.prediction.confusion_matrix (prediction.py:204-222), incl. its raw-label indexing."""
+    t = np.ascontiguousarray(truelbl, np.int64).ravel()
+    q = np.ascontiguousarray(predictedlbl, np.int64).ravel()
+    assert t.size == q.size
+    k = lib().orc_confusion_matrix(_p(t), _p(q), t.size, None)
+    if k < 0:
+        raise ValueError("zero-size array to reduction operation maximum which has no identity")
+    cnf = np.zeros((k, k), np.int64)
+    if lib().orc_confusion_matrix(_p(t), _p(q), t.size, _p(cnf)) < 0:
+        raise IndexError("label out of bounds for the confusion matrix")
+    return cnf
+
+
+def filter_segments(array: np.ndarray, min_len: int = 50) -> np.ndarray:
+    """deepgrp.prediction.filter_segments (prediction.py:244-260) on a copy; returns the filtered labels."""
+    a = np.ascontiguousarray(array, np.int64).copy()
+    lib().orc_filter_segments(_p(a), a.size, int(min_len))
+    return a
 
 
 # --------------------------------------------------------------------------- A4
