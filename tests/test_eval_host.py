@@ -155,3 +155,119 @@ def test_load_onehot_npz_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         load_onehot_npz(tmp_path / "bad.npz")
     del dgsequence
+
+
+# ------------------------------------------------------------------------- scripts (N4)
+def test_parse_rm_reference_fixture(tmp_path):
+    """The reference's own fixture pair (tests/test_parse_rm_input.out -> tests/test_parse_rm_expect.bed, data files
+    copied under tests/golden/, the input gzip-compressed), driven like its tests/test_parse_rm.py."""
+    import gzip, os
+    from conftest import GOLDEN
+    from deepgrp_amd._scripts import parse_rm
+    src = tmp_path / "input.out"
+    src.write_bytes(gzip.open(os.path.join(GOLDEN, "parse_rm_input.out.gz"), "rb").read())
+    out = tmp_path / "results.bed"
+    parse_rm.main(["-o", str(out), str(src)])
+    assert out.read_text() == open(os.path.join(GOLDEN, "parse_rm_expect.bed")).read()
+
+
+def test_parse_rm_formats_and_hsat2(capsys, tmp_path):
+    from deepgrp_amd._scripts import parse_rm
+    ex, off = parse_rm.pentamer_sets()
+    assert len(ex) == 10 and "GGAAT" in ex and "ATTCC" in ex and "AATGG" in ex
+    lines = [
+        "  693  29.9 10.1  6.3  chr21     9411195 9411890 (38718005) C  L1MEg          LINE/L1             (5558) 1775   1250 4456451\n",
+        "   12  25.2  5.2  1.7  chr21     9412401 9412458 (38717437) +  (TATAT)n       Simple_repeat            1   60    (0) 4456452\n",
+        "   50  10.0  0.0  0.0  chr1      101 200 (5) +  (GGAATGGAAC)n  Simple_repeat  1 100 (0) 7\n",        # exact + one-off
+        "   50  10.0  0.0  0.0  chr1      101 200 (5) +  (GGAACGGAAC)n  Satellite  1 100 (0) 8\n",           # one-off only
+        "   50  10.0  0.0  0.0  chr1      301 400 (5) +  (CATTC)n  Satellite  1 100 (0) 9\n",               # rotation of the rc
+        "585\t463\t13\t6\t17\tchr2\t1000\t1300\t-500\t-\tAluSx\tSINE\tAlu\n",                                 # rmsk, class != family
+        "585\t463\t13\t6\t17\tchr2\t2000\t2300\t-500\t+\tHSATII\tSatellite\tSatellite\n",                    # rmsk, by repeat name
+        "585\t463\t13\t6\t17\tchr2\t3000\t3300\t-500\t+\tFoo\tDNA\tDNA\n",                                   # unnumbered
+        "SW  perc perc perc  query  position in query\n",
+        "\n",
+    ]
+    got = [str(r) for r in parse_rm.read_repeatmasker(ex, off, lines)]
+    assert got == ["chr21\t9411194\t9411890\t4\tL1MEg\tLINE/L1",
+                   "chr1\t100\t200\t1\t(GGAATGGAAC)n\tSimple_repeat",
+                   "chr1\t300\t400\t1\t(CATTC)n\tSatellite",
+                   "chr2\t1000\t1300\t3\tAluSx\tSINE/Alu",
+                   "chr2\t2000\t2300\t1\tHSATII\tSatellite"]
+    src = tmp_path / "in.out"
+    src.write_text("".join(lines))
+    parse_rm.main([str(src)])
+    assert capsys.readouterr().out.splitlines() == got
+
+
+def test_preprocess_sequence_script(tmp_path):
+    """tests/test_preprocess_sequence.py of the reference (same input, expected array and md5), plus the rebuild
+    rules and the KeyError on other letters."""
+    import gzip, os
+    from deepgrp_amd._scripts import preprocess_sequence
+    from deepgrp_amd.preprocessing import load_onehot_npz
+    out = tmp_path / "inputs.fa.gz.npz"
+    src = tmp_path / "inputs.fa.gz"
+    with gzip.open(src, "w") as fh:
+        fh.write(">test\nACGTNACGTN\n".encode("utf-8"))
+    preprocess_sequence.main([str(src)])
+    got = np.load(out)
+    expected = [[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 0, 1, 0], [0, 0, 0, 0, 1]] * 2
+    np.testing.assert_array_equal(got["fwd"], np.array(expected).T)
+    assert got["fwd"].dtype == np.int8
+    assert got["hash"][0] == "ff8ed7aaa145d49602bf5fdf5e5b8338"
+    np.testing.assert_array_equal(load_onehot_npz(out), got["fwd"])
+    stamp = os.path.getmtime(out)
+    os.utime(out, (stamp - 100, stamp - 100))
+    preprocess_sequence.main([str(src)])                         # unchanged hash: not rewritten
+    assert os.path.getmtime(out) == stamp - 100
+    preprocess_sequence.main([str(src), "--force"])
+    assert os.path.getmtime(out) > stamp - 100
+    with gzip.open(src, "w") as fh:
+        fh.write(b">test\nacgt\nNN\n")                           # lower case is upper-cased, hash over the raw lines
+    preprocess_sequence.main([str(src)])
+    got = np.load(out)
+    np.testing.assert_array_equal(got["fwd"].argmax(axis=0), [0, 1, 2, 3, 4, 4])
+    with gzip.open(src, "w") as fh:
+        fh.write(b">test\nACGR\n")
+    with pytest.raises(KeyError):
+        preprocess_sequence.main([str(src)])
+    with pytest.raises(SystemExit):
+        preprocess_sequence.main([str(tmp_path / "missing.fa.gz")])
+
+
+def test_preprocess_y_reference_case(tmp_path):
+    """The case of the reference's tests/test_preprocessing.py:13-31."""
+    from deepgrp_amd.preprocessing import preprocess_y
+    rows = [["chr1", 5, 10, 2, "X"], ["chr2", 6, 11, 5, "X"], ["chr1", 13, 15, 4, "X"], ["chr1", 16, 18, 7, "X"]]
+    path = tmp_path / "data.bed"
+    path.write_text("".join("\t".join(str(c) for c in r) + "\n" for r in rows))
+    got = preprocess_y(filename=str(path), chromosom="chr1", length=20, repeats_to_search=[1, 2, 3, 4])
+    expected = np.zeros((5, 20))
+    expected[0, :5] = 1
+    expected[2, 5:10] = 1
+    expected[0, 10:13] = 1
+    expected[4, 13:15] = 1
+    expected[0, 15:] = 1
+    np.testing.assert_equal(got, expected)
+
+
+@pytest.mark.parametrize("start_n", (0, 10, 20))
+@pytest.mark.parametrize("end_n", (0, 10, 20))
+def test_drop_start_end_n_reference_case(start_n, end_n):
+    """tests/test_preprocessing.py:34-53 of the reference, incl. the dropped last base."""
+    from deepgrp_amd.preprocessing import drop_start_end_n
+    testdata = np.zeros((5, 100))
+    if end_n == 0:
+        testdata[1, start_n:] = 1
+    else:
+        testdata[1, start_n:-end_n] = 1
+        testdata[4, -end_n:] = 1
+    testdata[4, :start_n] = 1
+    truelbl = np.arange(100).reshape((1, 100))
+    got_x, got_y = drop_start_end_n(testdata, truelbl)
+    assert got_y.shape == (1, 100 - start_n - end_n - 1)
+    assert got_x.shape == (5, 100 - start_n - end_n - 1)
+    np.testing.assert_equal(got_x.sum(axis=1), [0, 100 - start_n - end_n - 1, 0, 0, 0])
+    assert got_y[0, 0] == start_n
+    assert got_y[0, -1] == 100 - end_n - 2
+    np.testing.assert_equal(got_y[0, :-1] - got_y[0, 1:], -1)
