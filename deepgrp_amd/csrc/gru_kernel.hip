@@ -662,6 +662,7 @@ struct att_params {
     int64_t n, s, w0, nw;
     dgrp_placement place;
     int T, C, UP, merge;
+    int ospan;           // wave kernel, merge: rows of the workgroup's LDS output image
 };
 
 // One workgroup (256 threads) per window, ONE pass over the window's avg[t] tile (read from HBM once):
@@ -669,6 +670,7 @@ struct att_params {
 // computed with lane <-> t (each wave a quarter of the units), the softmax over t is kept online
 // (running max / sum, context rescaled per tile), the context update runs with thread <-> unit.
 #define ATT_TT 64
+#define ATT_WPB 16                                       // windows per workgroup of the wave kernel below
 __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -759,6 +761,191 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
             } else {
                 p.out[(row0 + t) * C + c] = v;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same computation with ONE WAVE per window and no workgroup barrier (units <= 128): the tile kernel above
+// spends its time in __syncthreads and in a context phase that keeps a quarter of the threads busy.  Here
+// lane <-> time step throughout: a lane reads its own avg[t] row (UP halves, contiguous) into registers, scores
+// it against q (packed math, two units per instruction; 2^(c(q+a)) with c folded into the LDS copy of q, and
+// tanh = 1 - 2r folded into the scale: e[t] = sum(scale) - 2 sum_k scale[k] r[k]), keeps the softmax over t
+// online, and accumulates its OWN share p[t] avg[t,:] of the context in registers; the 64 per-lane partial
+// contexts meet once per window in a 6-stage halving butterfly (after stage xor-M a lane keeps the half of the
+// units whose bit M equals its own lane bit) that leaves unit k's total in lane k.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_allmax(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+    return x;
+}
+__device__ __forceinline__ float wave_allsum(float x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+template <int UP>
+__global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params p)
+{
+    constexpr int CT = UP <= 64 ? 64 : 128;                  // context registers per lane (butterfly width)
+    __shared__ __attribute__((aligned(16))) float qs[4][UP][2];   // per wave: {c*q[k], -2*scale[k]}
+    __shared__ __attribute__((aligned(16))) _Float16 tile[4][64][UP + 8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_dyn[];
+    unsigned *obuf = reinterpret_cast<unsigned *>(att_dyn);  // merge: max image of the rows the 16 windows cover
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int T = p.T, C = p.C;
+    const int64_t wg0 = (int64_t)blockIdx.x * ATT_WPB;       // a workgroup owns 16 consecutive windows, 4 per wave
+    const int nvalid = (int)min((int64_t)ATT_WPB, p.nw - wg0);
+    int64_t lo = 0;
+    if (p.merge) {
+        const int64_t a = dgrp_place_row(p.place, p.w0 + wg0, p.s), b = dgrp_place_row(p.place, p.w0 + wg0 + nvalid - 1, p.s);
+        lo = a < b ? a : b;
+        for (int i = threadIdx.x; i < p.ospan * C; i += 256) obuf[i] = 0u;
+        __syncthreads();
+    }
+    constexpr float C2 = 2.8853900817779268f;                // 2 log2 e
+  for (int wi = wave; wi < nvalid; wi += 4) {
+    const int64_t wl = wg0 + wi;
+    const _Float16 *avg = p.avg + wl * (int64_t)T * UP;
+    float ssum = 0.0f;
+    for (int k = lane; k < UP; k += 64) {
+        const float sc = p.scale[k];
+        qs[wave][k][0] = C2 * (float)avg[(int64_t)(T - 1) * UP + k];      // Average of the two final states = avg[T-1]
+        qs[wave][k][1] = -2.0f * sc;
+        ssum += sc;
+    }
+    ssum = wave_allsum(ssum);
+    float ctx[CT];
+#pragma unroll
+    for (int k = 0; k < CT; ++k) ctx[k] = 0.0f;
+    float run_m = -INFINITY, run_l = 0.0f;
+    // a tile of 64 steps is fetched with fully coalesced 16-byte loads (1 KiB per wave instruction; a lane reading
+    // its own 2*UP-byte row would touch 64 cache lines per instruction and thrash the 16 KiB L1), one tile ahead,
+    // and turned into row-per-lane through the wave's private LDS tile (pitch UP + 8 halves: conflict-free both ways)
+    constexpr int CPR = UP / 8, TP = UP + 8;                 // 16-byte chunks per row, LDS row pitch
+    _Float16 *mytile = &tile[wave][0][0];
+    half8 nxt[CPR];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < CPR; ++j) {
+            const int c = j * 64 + lane, r = c / CPR;
+            nxt[j] = t0 + r < T ? *reinterpret_cast<const half8 *>(avg + (int64_t)t0 * UP + (int64_t)c * 8) : half8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+        }
+    };
+    constexpr bool AHEAD = UP <= 64;                         // beyond 64 units the registers for a tile in flight are gone
+    if (AHEAD) fetch(0);
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const bool ok = t < T;
+        if (!AHEAD) fetch(t0);
+#pragma unroll
+        for (int j = 0; j < CPR; ++j) {
+            const int c = j * 64 + lane;
+            *reinterpret_cast<half8 *>(mytile + (c / CPR) * TP + (c % CPR) * 8) = nxt[j];
+        }
+        if (AHEAD && t0 + 64 < T) fetch(t0 + 64);
+        half8 row[CPR];
+#pragma unroll
+        for (int j = 0; j < CPR; ++j) row[j] = *reinterpret_cast<const half8 *>(mytile + lane * TP + j * 8);
+        f32x2 acc = { 0.0f, 0.0f };
+        // (the offset is laundered so that the 2 UP loop-invariant LDS values are re-read per tile instead of
+        // living in registers for the whole kernel)
+        int qoff = wave * UP * 2;
+        asm volatile("" : "+v"(qoff));
+        const float *qw = &qs[0][0][0] + qoff;
+#pragma unroll
+        for (int k0 = 0; k0 < UP; k0 += 16) {                // 8 broadcast reads in flight, then 8 unit pairs
+            f32x4 qv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qv[i] = *reinterpret_cast<const f32x4 *>(qw + 2 * (k0 + 2 * i));      // same address in every lane
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = k0 + 2 * i;
+                const f32x2 a = { (float)row[k / 8][k % 8], (float)row[k / 8][k % 8 + 1] };
+                const f32x2 x = a * C2 + f32x2{ qv[i][0], qv[i][2] };
+                const f32x2 r = rcp1p_exp2_pair(x.x, x.y);
+                acc = r * f32x2{ qv[i][1], qv[i][3] } + acc;
+            }
+        }
+        const float et = ok ? ssum + acc.x + acc.y : -INFINITY;
+        const float new_m = fmaxf(run_m, wave_allmax(et));
+        const float alpha = __builtin_amdgcn_exp2f(1.4426950408889634f * (run_m - new_m));      // 0 on the first tile
+        const float pt = ok ? __builtin_amdgcn_exp2f(1.4426950408889634f * (et - new_m)) : 0.0f;
+        run_l = run_l * alpha + wave_allsum(pt);
+        run_m = new_m;
+#pragma unroll
+        for (int j = 0; j < CPR; ++j) asm volatile("" : "+v"(row[j]));      // convert again rather than keep UP floats alive
+#pragma unroll
+        for (int k = 0; k < UP; k += 2) {
+            const f32x2 a = { (float)row[k / 8][k % 8], (float)row[k / 8][k % 8 + 1] };
+            const f32x2 c = f32x2{ ctx[k], ctx[k + 1] } * alpha + a * pt;
+            ctx[k] = c.x; ctx[k + 1] = c.y;
+        }
+    }
+    // ---- butterfly: lane l ends with the window's context for unit l (and unit l + 64 when CT = 128)
+#pragma unroll
+    for (int base = 0; base < CT; base += 64) {
+#pragma unroll
+        for (int h = 64; h > 1; h >>= 1) {
+            const int m = h >> 1;                            // partner = lane ^ m, keep the half that matches our bit m
+            const bool up = (lane & m) != 0;
+#pragma unroll
+            for (int j = 0; j < m; ++j) {
+                const float keep = up ? ctx[base + j + m] : ctx[base + j];
+                const float send = up ? ctx[base + j] : ctx[base + j + m];
+                ctx[base + j] = keep + __shfl_xor(send, m);
+            }
+        }
+    }
+    const float inv = __builtin_amdgcn_rcpf(run_l);
+    float ctop[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float part = 0.0f;
+        if (c < C) {
+            if (lane < UP) part = ctx[0] * p.wtop[lane * 16 + c];
+            if (CT == 128 && lane + 64 < UP) part += ctx[64] * p.wtop[(lane + 64) * 16 + c];
+            part = wave_allsum(part) * inv;
+        }
+        ctop[c] = part;
+    }
+    // ---- logits[t] = ctx.W_top + (avg[t].W_bot + b), softmax over classes, merge / store: lane <-> t
+    const int64_t row0 = p.merge ? dgrp_place_row(p.place, p.w0 + wl, p.s) : wl * (int64_t)T;
+    const int off = p.merge && row0 >= lo && row0 - lo + T <= p.ospan ? (int)(row0 - lo) : -1;
+    const float *pl = p.pl + wl * (int64_t)T * C;
+    for (int t = lane; t < T; t += 64) {
+        float lg[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) { lg[c] = pl[(int64_t)t * C + c] + ctop[c]; mx = fmaxf(mx, lg[c]); }
+        float den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) { lg[c] = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg[c] - mx)); den += lg[c]; }
+        const float rden = __builtin_amdgcn_rcpf(den);
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) {
+                const float v = lg[c] * rden;
+                if (!p.merge) p.out[(row0 + t) * C + c] = v;
+                else if (off >= 0) lds_atomic_max(obuf + (off + t) * C + c, __float_as_uint(v));
+                else if (row0 + t < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
+            }
+    }
+  }
+    if (p.merge && p.ospan > 0) {
+        __syncthreads();
+        // flush the pre-merged image: contiguous rows -> full-line atomic wave-instructions (as the GRU kernel does)
+        unsigned *gout = reinterpret_cast<unsigned *>(p.out) + lo * C;
+        const int64_t lim = (p.n - lo) * C;
+        for (int i = threadIdx.x; i < p.ospan * C; i += 256) {
+            const unsigned v = obuf[i];
+            if (v != 0u && i < lim) global_atomic_max(gout + i, v);
         }
     }
 }
@@ -895,6 +1082,29 @@ int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, 
     p.T = m->T; p.C = m->C; p.UP = m->UP; p.merge = merge;
     const size_t lds = (size_t)ATT_TT * (m->UP + 8) * 2 + (size_t)(3 * m->UP + 4 * ATT_TT + ATT_TT + 8 + 16) * sizeof(float);
     DGRP_REQUIRE(nw < (1ll << 31), "too many windows in one launch");
+    p.ospan = 0;
+    const int64_t want = (ATT_WPB - 1) * s + m->T;
+    const unsigned grid = (unsigned)((nw + ATT_WPB - 1) / ATT_WPB);
+    if (m->UP <= 64 && !getenv("DGRP_ATT_TILE")) {
+        // one wave per window; beyond 64 units its per-lane context (UP registers) no longer fits beside the row
+        const int stat = 4 * m->UP * 2 * 4 + 4 * 64 * (m->UP + 8) * 2;           // qs + tiles (static LDS of the kernel)
+        if (merge) {
+            const int64_t cap = (78 * 1024 - stat) / (m->C * 4);                 // two workgroups per CU
+            p.ospan = (int)(want < cap ? want : cap);
+            if (p.ospan < m->T) p.ospan = 0;
+        }
+        const size_t dyn = (size_t)p.ospan * m->C * 4;
+        static bool configured = false;
+        if (!configured) {                                   // static + dynamic LDS may use the whole 160 KiB
+            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (4 * 32 * 8 + 256 * 40 * 2)));
+            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (4 * 64 * 8 + 256 * 72 * 2)));
+            configured = true;
+        }
+        if (m->UP == 32) hipLaunchKernelGGL(attention_wave_kernel<32>, dim3(grid), dim3(256), dyn, stream, p);
+        else hipLaunchKernelGGL(attention_wave_kernel<64>, dim3(grid), dim3(256), dyn, stream, p);
+        DGRP_LAUNCH_CHECK();
+        return DGRP_OK;
+    }
     hipLaunchKernelGGL(attention_kernel, dim3((unsigned)nw), dim3(256), lds, stream, p);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
