@@ -344,14 +344,27 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         const half8 xa = __builtin_bit_cast(half8, xu);
 
         const _Float16 *arow = hcur + r * HS + 8 * khalf;
-        half8 af[KS];
+        // u <= 128: the KS fragments of h_{t-1} are read once and serve all three chains.  Beyond, they alone
+        // would take 64+ VGPRs next to two resident gate slices: every chain re-reads them from LDS instead
+        // (3 x 16 KB per wave-step, well inside the LDS rate next to 51 MFMAs).
+        half8 af[ZSTREAM ? 1 : KS];
+        if (!ZSTREAM) {
 #pragma unroll
-        for (int k = 0; k < KS; ++k) af[k] = *reinterpret_cast<const half8 *>(arow + 16 * k);
+            for (int k = 0; k < KS; ++k) af[k] = *reinterpret_cast<const half8 *>(arow + 16 * k);
+        }
+        auto hfrag = [&](int k) -> half8 { return ZSTREAM ? *reinterpret_cast<const half8 *>(arow + 16 * k) : af[ZSTREAM ? 0 : k]; };
+        // the streamed z fragments: ZPF of them in flight, the first ones requested before the g chain
+        constexpr int ZPF = 4;
+        uint4 zq[ZSTREAM ? ZPF : 1];
+        if (ZSTREAM) {
+#pragma unroll
+            for (int i = 0; i < ZPF; ++i) zq[i] = mypack[(size_t)i * 64];
+        }
         f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
         if (STAGED) finish_stage(0, t);                      // (steps 0 and 1 run the stages on stale data, uncommitted)
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], af[k], ar, 0, 0, 0);
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], hfrag(k), ar, 0, 0, 0);
             if (STAGED) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -373,7 +386,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         f32x2 rr[8];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], af[k], ag, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], hfrag(k), ag, 0, 0, 0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 2 * (k * 8 / KS); i < 2 * ((k + 1) * 8 / KS); i += 2) {
@@ -389,8 +402,9 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         f32x2 hh[8];
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
-            const half8 bz = ZSTREAM ? __builtin_bit_cast(half8, mypack[(size_t)k * 64]) : Bz[k];
-            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(bz, af[k], az, 0, 0, 0);
+            const half8 bz = ZSTREAM ? __builtin_bit_cast(half8, zq[ZSTREAM ? k % ZPF : 0]) : Bz[ZSTREAM ? KS : k];
+            if (ZSTREAM && k + ZPF < KS) zq[ZSTREAM ? k % ZPF : 0] = mypack[(size_t)(k + ZPF) * 64];
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(bz, hfrag(k), az, 0, 0, 0);
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
             if (k < KH) {
 #pragma unroll
