@@ -353,8 +353,9 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
             for (int k = 0; k < KS; ++k) af[k] = *reinterpret_cast<const half8 *>(arow + 16 * k);
         }
         auto hfrag = [&](int k) -> half8 { return ZSTREAM ? *reinterpret_cast<const half8 *>(arow + 16 * k) : af[ZSTREAM ? 0 : k]; };
-        // the streamed z fragments: ZPF of them in flight, the first ones requested before the g chain
-        constexpr int ZPF = 4;
+        // the streamed z fragments: ZPF of them in flight, the first ones requested before the g chain (same box, u=256:
+        // 8 deep 157 ms, 4 deep 116, 2 deep 105, 1 deep 104 per 5 Mbp -- spilled registers cost more than exposed latency)
+        constexpr int ZPF = NW >= 7 ? 2 : 4;                 // 224+ units spill: every register counts more than latency
         uint4 zq[ZSTREAM ? ZPF : 1];
         if (ZSTREAM) {
 #pragma unroll
