@@ -166,8 +166,14 @@ class CommandLineParser:
             outstream = sys.stdout if args.output == "-" else open(args.output, "w")
 
         def rows_text(filename: str, header: str, rows) -> str:
-            return "".join("{}\t{}\t{}\t{}\t{}\n".format(filename, header, int(r["start"]), int(r["end"]), int(r["label"]))
-                           for r in rows)
+            """The TSV rows of one record (__main__.py:291-292), built column-wise: integer -> text and the
+            concatenations are numpy loops, not one str.format per row."""
+            if len(rows) == 0:
+                return ""
+            prefix = "{}\t{}\t".format(filename, header)
+            cols = [rows[name].astype(np.int64).astype("U") for name in ("start", "end", "label")]
+            body = np.char.add(np.char.add(np.char.add(np.char.add(cols[0], "\t"), cols[1]), "\t"), cols[2])
+            return prefix + ("\n" + prefix).join(body.tolist()) + "\n"
 
         def run_record(rec, contig=0):
             if isinstance(rec, DeviceRecord):                 # parsed and encoded on the GPU
@@ -187,10 +193,45 @@ class CommandLineParser:
             else:
                 yield from read_multi_fasta_device(filename)
 
+        def one_ahead(gen):
+            """Iterate `gen` from a helper thread, one item ahead: the next record is located, uploaded and encoded
+            (on a side stream) while the current one is on the GPU.  An exception of the generator surfaces at the
+            position in the sequence where it occurred, as without the thread."""
+            import queue
+            import threading
+            q: "queue.Queue" = queue.Queue(maxsize=1)
+            done = object()
+            dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+            def work():
+                try:
+                    if dev is not None:
+                        torch.cuda.set_device(dev)
+                        side = torch.cuda.Stream()
+                        with torch.cuda.stream(side):
+                            for item in gen:
+                                side.synchronize()
+                                q.put(item)
+                    else:
+                        for item in gen:
+                            q.put(item)
+                    q.put(done)
+                except BaseException as exc:      # noqa: BLE001  handed to the consumer
+                    q.put(exc)
+
+            threading.Thread(target=work, daemon=True).start()
+            while True:
+                item = q.get()
+                if item is done:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+
         if world == 1:
             for filename in args.FASTA:
                 _LOG.info("Processing %s", filename)
-                for header, rec in records_of(filename):
+                for header, rec in one_ahead(records_of(filename)):
                     outstream.write(rows_text(filename, header, run_record(rec)))
         else:
             # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
