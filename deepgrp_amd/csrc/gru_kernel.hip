@@ -49,7 +49,6 @@ struct gru_params {
     int T, C, nfrag, mode;
     int Tp;               // T rounded up to 16 (row pitch of the staged sequences)
     int ospan;            // rows of the LDS output image (mode 0), 0 = none
-    int delay, delay_mode; // experiment: one-time start delay of the second workgroup slot
     uint64_t *stamps;
 };
 
@@ -148,17 +147,6 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     const int64_t wg_w = p.w0 + (int64_t)blockIdx.x * DGRP_WG_WINDOWS;   // first window of this workgroup
     const int nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - wg_w);
 
-    if (p.delay > 0 && blockIdx.x < 512) {
-        bool late;
-        if (p.delay_mode == 0) late = (blockIdx.x >> 8) & 1;
-        else {
-            if (tid == 0) rowoff[0] = __builtin_amdgcn_s_getreg(6148) & 1;      // HW_ID.wave_id parity
-            __syncthreads();
-            late = rowoff[0];
-            __syncthreads();
-        }
-        if (late) for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     // ---- resident B fragments ------------------------------------------------------------
     const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
     half8 Bz[KS + 1], Br[KS + 1], Bg[KS + 1], Bxh, Bd_hi, Bd_lo;
@@ -1036,7 +1024,6 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
         p.stamps = d_stamps;
     }
 #endif
-    { const char *e = getenv("DGRP_GRU_DELAY"); p.delay = e ? atoi(e) : 0; e = getenv("DGRP_GRU_DELAY_MODE"); p.delay_mode = e ? atoi(e) : 0; }
     const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
     p.ospan = 0;
     if (mode == 0) {
