@@ -5,29 +5,34 @@
 //   reverse-complement --> GRU --> rc[t]  --+      (same layer object => shared weights; rc is NOT
 //                                                   re-reversed: model.py:309-312, :321-323)
 //
-// Work decomposition (u <= 128; UP = u rounded up to 32, NW = UP/32 waves per workgroup):
+// Work decomposition (UP = u rounded up to 32, NW = UP/32 waves per workgroup):
 //   * a workgroup owns 16 consecutive windows = 32 recurrent rows (rows 0-15 the windows, rows
 //     16-31 their reverse complements), i.e. one 32-row MFMA tile, for all T steps;
 //   * wave w owns hidden units [32w, 32w+32) of ALL THREE gates, so z, r and the candidate of one
 //     (row, unit) land in the same lane/register of three accumulators and the gate math needs no
 //     cross-lane traffic;
 //   * the wave's slice of the recurrent kernel U (K = UP rows x 96 columns) lives in VGPRs for the
-//     whole kernel as v_mfma_f32_32x32x16_f16 B fragments (112 VGPRs at u = 128) -- nothing but
-//     the 8 KB hidden-state tile moves per step, through LDS;
-//   * the input projection is one extra 16-deep k-step: A = one-hot(base) with a constant-1 column,
-//     B rows = kernel rows and biases, each split into fp16 hi + lo parts (exact products, fp32
+//     whole kernel as v_mfma_f32_32x32x16_f16 fragments (112 VGPRs at u = 128) -- nothing but the
+//     8 KB hidden-state tile moves per step, through LDS.  The tile is computed TRANSPOSED (weights
+//     are the A operand, h the B operand: D[unit][row]), so a lane holds 4 x 4 consecutive units of one
+//     row and publishes them with packed converts and four 8-byte stores.  Beyond 128 units the z slice
+//     streams from L2 and the fragments of h are re-read per chain (see the loop);
+//   * the input projection is one extra 16-deep k-step: one-hot(base) with a constant-1 column
+//     against kernel rows and biases, each split into fp16 hi + lo parts (exact products, fp32
 //     accumulate => ~fp32-exact projection for free);
 //   * the candidate's  x.W_h + b  lands on top of  r * (h.U_h + b_rec)  by feeding r*g as the C
 //     operand of that MFMA -- no separate accumulator;
-//   * Dense(C) is two v_mfma_f32_16x16x32_f16 per wave per step on the wave's own 32 units of the
-//     fresh hidden tile (fwd rows accumulate onto rc rows = the Average), partial sums meet in LDS
-//     and a rotating "duty" wave adds them, applies the softmax and max-merges into a per-workgroup
+//   * Dense(C) is four v_mfma_f32_16x16x32_f16 per wave per step on the wave's own 32 units of the
+//     hidden tile (fwd rows accumulate onto rc rows = the Average), issued ONE STEP LATE behind the next
+//     step's r chain; partial sums meet in LDS, every wave finishes a quarter of the 16 x C tile
+//     (softmax over the class lanes by DPP) another step later and max-merges into a per-workgroup
 //     LDS image of the [rows, C] output (get_max, deepgrp/maxcalc.c:10-24), flushed once at the end
 //     with full-line atomic max (probabilities are >= 0, so unsigned-int max == float max).
 //
-// Roofline: 12 u^2 T flop per window on the MFMA pipe, but 6 transcendentals per (row, unit, step)
-// on the VALU pipe are of the same order; two workgroups per CU let one's MFMAs
-// overlap the other's gate math.
+// Roofline: 12 u^2 T flop per window on the MFMA pipe; what binds is the SIMD's vector issue port
+// (5-6 transcendentals and ~8 plain operations per (row, unit, step)): a wave issues
+// in order and waits for the matrix pipe at every back-to-back MFMA, so the gate math of one chain
+// is placed in the gaps of the next chain in program order; two workgroups per CU share each SIMD.
 #include "dgrp_model.h"
 #include <vector>
 
