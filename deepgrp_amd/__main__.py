@@ -193,46 +193,51 @@ class CommandLineParser:
             else:
                 yield from read_multi_fasta_device(filename)
 
-        def one_ahead(gen):
-            """Iterate `gen` from a helper thread, one item ahead: the next record is located, uploaded and encoded
-            (on a side stream) while the current one is on the GPU.  An exception of the generator surfaces at the
-            position in the sequence where it occurred, as without the thread."""
-            import queue
+        def in_order(records, fn, workers: int = 8, max_bases: int = 1 << 31):
+            """`fn(record)` for every (header, record) of the iterable on a small pool of threads, each with its own
+            HIP stream; yields (header, result) in input order.  Records are independent (__main__.py:280-292), so
+            while one is in its post-processing (whose fixed-point loop waits on the stream) the next ones are
+            already on the GPU, and a file of many short records no longer pays a launch-and-wait chain each.
+            The bases in flight are bounded; an exception surfaces where the sequential loop would raise it."""
+            import collections
             import threading
-            q: "queue.Queue" = queue.Queue(maxsize=1)
-            done = object()
+            from concurrent.futures import ThreadPoolExecutor
             dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+            local = threading.local()
 
-            def work():
-                try:
-                    if dev is not None:
-                        torch.cuda.set_device(dev)
-                        side = torch.cuda.Stream()
-                        with torch.cuda.stream(side):
-                            for item in gen:
-                                side.synchronize()
-                                q.put(item)
-                    else:
-                        for item in gen:
-                            q.put(item)
-                    q.put(done)
-                except BaseException as exc:      # noqa: BLE001  handed to the consumer
-                    q.put(exc)
+            def task(rec):
+                if dev is None:
+                    return fn(rec)
+                if not hasattr(local, "stream"):
+                    torch.cuda.set_device(dev)
+                    local.stream = torch.cuda.Stream()
+                with torch.cuda.stream(local.stream):
+                    out = fn(rec)
+                    local.stream.synchronize()
+                return out
 
-            threading.Thread(target=work, daemon=True).start()
-            while True:
-                item = q.get()
-                if item is done:
-                    return
-                if isinstance(item, BaseException):
-                    raise item
-                yield item
+            size = lambda r: r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
+            pending: "collections.deque" = collections.deque()
+            inflight = 0
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                for header, rec in records:
+                    w = size(rec)
+                    while pending and (inflight + w > max_bases or len(pending) >= 4 * workers):
+                        h0, f0, w0 = pending.popleft()
+                        yield h0, f0.result()
+                        inflight -= w0
+                    pending.append((header, pool.submit(task, rec), w))
+                    inflight += w
+                    del rec
+                while pending:
+                    h0, f0, w0 = pending.popleft()
+                    yield h0, f0.result()
 
         if world == 1:
             for filename in args.FASTA:
                 _LOG.info("Processing %s", filename)
-                for header, rec in one_ahead(records_of(filename)):
-                    outstream.write(rows_text(filename, header, run_record(rec)))
+                for header, rows in in_order(records_of(filename), run_record):
+                    outstream.write(rows_text(filename, header, rows))
         else:
             # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
             records = []
