@@ -233,6 +233,38 @@ def test_cli_end_to_end(orc, tmp_path, argv_style, use_mss):
     assert want.count("\n") > 3
 
 
+def test_cli_many_records_ordered_and_errors_in_place(orc, tmp_path):
+    """40 records of mixed lengths go through the CLI's thread/stream pool: the TSV is the sequential pipeline's,
+    record by record in file order; an all-N record in the middle raises the reference's ValueError
+    (sequence.pyx:27-32) after the rows of the records before it have been written."""
+    from deepgrp_amd.__main__ import main
+    rng = np.random.default_rng(77)
+    recs = {}
+    for k in range(40):
+        n = int(rng.choice([5, 29, 31, 64, 200, 777, 3000, 12000]))
+        recs[f"ctg{k} len={n}"] = "".join(rng.choice(list("ACGTn"), size=n, p=[.24, .24, .24, .24, .04])).strip("n") or "A"
+    fasta = tmp_path / "many.fa"
+    text = lambda d: "".join(f">{h}\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n" for h, s in d.items())
+    fasta.write_text(text(recs))
+    model_file = os.path.join(GOLDEN, "model_u16_T30_att_vlen.h5")
+    out = tmp_path / "out.tsv"
+    main(["-b", "7", "-s", "4", "-x", "5", "-l", "3", "predict", model_file, str(fasta), "--output", str(out)])
+    want = _expected_tsv(orc, str(fasta), model_file, None, 4, 7, 3, 5, True)
+    assert out.read_text() == want
+    # an all-N record after 25 good ones
+    items = list(recs.items())
+    bad = dict(items[:25] + [("allN", "NNNNNNNN")] + items[25:])
+    fasta2 = tmp_path / "bad.fa"
+    fasta2.write_text(text(bad))
+    out2 = tmp_path / "out2.tsv"
+    with pytest.raises(ValueError, match="negative dimensions"):
+        main(["-b", "7", "-s", "4", "-x", "5", "-l", "3", "predict", model_file, str(fasta2), "--output", str(out2)])
+    head = tmp_path / "head.fa"
+    head.write_text(text(dict(items[:25])))
+    want_head = _expected_tsv(orc, str(head), model_file, None, 4, 7, 3, 5, True).replace(str(head), str(fasta2))
+    assert out2.read_text() == want_head
+
+
 def test_cli_with_lstm_model(orc, tmp_path):
     """`deepgrp predict` with an rnn="LSTM" model file: rows equal the oracle's post-processing of the
     GPU probabilities, probabilities within 1e-3 of the float64 LSTM statement."""
