@@ -193,7 +193,7 @@ class CommandLineParser:
             else:
                 yield from read_multi_fasta_device(filename)
 
-        def in_order(records, fn, workers: int = 8, max_bases: int = 1 << 31):
+        def in_order(records, fn, workers: int = int(os.environ.get("DGRP_CLI_WORKERS", "16")), max_bases: int = 1 << 31):
             """`fn(record)` for every (header, record) of the iterable on a small pool of threads, each with its own
             HIP stream; yields (header, result) in input order.  Records are independent (__main__.py:280-292), so
             while one is in its post-processing (whose fixed-point loop waits on the stream) the next ones are

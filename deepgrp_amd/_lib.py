@@ -28,6 +28,8 @@ _SIGNATURES = {
     "dgrp_onehot": (cint, [vp, i64, vp, vp]),
     "dgrp_fasta_workspace_bytes": (i64, [i64]),
     "dgrp_fasta_encode": (cint, [vp, i64, vp, C.POINTER(i64), vp, i64, vp]),
+    "dgrp_fasta_batch_workspace_bytes": (i64, [i64, i64]),
+    "dgrp_fasta_encode_batch": (cint, [vp, i64, vp, vp, vp, vp, vp, i64, vp]),
     "dgrp_window_count": (i64, [i64, i64, i64]),
     "dgrp_windows_onehot": (cint, [vp, i64, i64, i64, i64, i64, cint, vp, vp]),
     "dgrp_model_create": (cint, [C.POINTER(vp), cint, cint, cint, cint, vp, vp, vp, vp, vp, vp]),
@@ -46,6 +48,8 @@ _SIGNATURES = {
     "dgrp_mss_segments_host": (cint, [vp, i64, vp, i64, C.POINTER(i64)]),
     "dgrp_segments_workspace_bytes": (i64, [i64]),
     "dgrp_segments": (cint, [vp, i64, i64, i32, vp, i64, vp, vp, i64, vp]),
+    "dgrp_record_workspace_bytes": (i64, [vp, i64, i64, cint]),
+    "dgrp_predict_record": (cint, [vp, vp, i64, i64, i64, cint, cint, cint, i64, i32, vp, i64, C.POINTER(i64), vp, i64, vp]),
     "dgrp_confusion_matrix": (cint, [vp, vp, i64, cint, vp, vp, vp]),
     "dgrp_filter_segments": (cint, [vp, vp, i64, i64, vp]),
 }

@@ -346,3 +346,91 @@ DGRP_EXPORT int dgrp_forward_merge(const dgrp_model *m, const uint8_t *d_idx, in
 {
     return forward_common(m, d_idx, n, s, batch, w0, nw, 1, d_out, d_work, work_bytes, (hipStream_t)stream);
 }
+
+// ---- the whole per-record chain of deepgrp/__main__.py:46-83 + :288-292 behind one call ---------------------
+// (A3-A11: windows -> forward -> max-merge -> scores / softmax -> MSS labels -> segments).  Everything lives in the
+// caller's workspace; a host thread per stream can run records concurrently with nothing but this call in between.
+static int64_t record_window_chunk(const dgrp_model *m)
+{
+    if (!m->attention) return 1ll << 20;
+    // keep the avg[t] spill of one launch below ~2 GiB (16-window granularity of the kernels)
+    const int64_t per = (int64_t)m->T * ((int64_t)m->UP * 2 + (int64_t)m->C * 4);
+    int64_t c = ((2ll << 30) / per) / 16 * 16;
+    if (c < 16) c = 16;
+    return c < (1ll << 20) ? c : (1ll << 20);
+}
+
+struct record_layout {
+    int64_t out, scores, cls, labels, count, fwd, post, bytes, post_bytes, fwd_bytes;
+};
+
+static record_layout record_carve(const dgrp_model *m, int64_t n, int64_t s, int use_mss)
+{
+    record_layout l;
+    int64_t p = 0;
+    auto take = [&](int64_t b) { const int64_t q = p; p += dgrp_align_up(b, 256); return q; };
+    const int64_t nwin = dgrp_window_count(n, m->T, s);
+    const int64_t chunk = std::min<int64_t>(record_window_chunk(m), nwin > 0 ? nwin : 1);
+    l.out = take(n * m->C * 4);
+    l.scores = take(use_mss ? n * 8 : 0);
+    l.cls = take(use_mss ? n : 0);
+    l.labels = take(n);
+    l.count = take(8);
+    l.fwd_bytes = std::max<int64_t>(dgrp_forward_workspace_bytes(m, chunk), 256);
+    l.fwd = take(l.fwd_bytes);
+    l.post_bytes = std::max<int64_t>(std::max<int64_t>(use_mss ? dgrp_mss_workspace_bytes(n) : 4096, dgrp_segments_workspace_bytes(n)), 4096);
+    l.post = take(l.post_bytes);
+    l.bytes = p;
+    return l;
+}
+
+DGRP_EXPORT int64_t dgrp_record_workspace_bytes(const dgrp_model *m, int64_t n, int64_t s, int use_mss)
+{
+    if (!m || n < 0 || s < 1) return 0;
+    return record_carve(m, n, s, use_mss).bytes;
+}
+
+DGRP_EXPORT int dgrp_predict_record(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch,
+                                    int min_mss_len, int xdrop_len, int use_mss, int64_t offset, int32_t contig,
+                                    dgrp_segment *d_records, int64_t cap, int64_t *h_count, void *d_work,
+                                    int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(m && n >= 0 && s >= 1 && batch >= 1 && cap >= 0 && h_count, "dgrp_predict_record: bad arguments");
+    *h_count = 0;
+    if (n == 0) return DGRP_OK;
+    DGRP_REQUIRE(d_idx && d_work && (cap == 0 || d_records), "dgrp_predict_record: NULL pointer");
+    const record_layout l = record_carve(m, n, s, use_mss);
+    if (work_bytes < l.bytes) {
+        dgrp_set_error("dgrp_predict_record: workspace %lld < %lld bytes", (long long)work_bytes, (long long)l.bytes);
+        return DGRP_ENOMEM;
+    }
+    char *w = (char *)d_work;
+    float *out = (float *)(w + l.out);
+    int8_t *labels = (int8_t *)(w + l.labels);
+    int64_t *d_count = (int64_t *)(w + l.count);
+    DGRP_HIP(hipMemsetAsync(out, 0, (size_t)n * m->C * 4, stream));                    // np.zeros, prediction.py:103
+    const int64_t nwin = dgrp_window_count(n, m->T, s);
+    const int64_t chunk = record_window_chunk(m);
+    for (int64_t w0 = 0; w0 < nwin; w0 += chunk) {
+        const int64_t nw = std::min<int64_t>(chunk, nwin - w0);
+        int rc = dgrp_forward_merge(m, d_idx, n, s, batch, w0, nw, out, w + l.fwd, l.fwd_bytes, stream);
+        if (rc) return rc;
+    }
+    int rc;
+    if (use_mss) {
+        rc = dgrp_scores(out, n, m->C, (double *)(w + l.scores), (int8_t *)(w + l.cls), stream);
+        if (rc) return rc;
+        rc = dgrp_mss_labels((const double *)(w + l.scores), (const int8_t *)(w + l.cls), n, m->C, min_mss_len, xdrop_len,
+                             labels, nullptr, w + l.post, l.post_bytes, stream);
+    } else {
+        rc = dgrp_softmax_labels(out, n, m->C, nullptr, labels, w + l.post, l.post_bytes, stream);
+    }
+    if (rc) return rc;
+    rc = dgrp_segments(labels, n, offset, contig, d_records, cap, d_count, w + l.post, l.post_bytes, stream);
+    if (rc) return rc;
+    DGRP_HIP(hipMemcpyAsync(h_count, d_count, 8, hipMemcpyDeviceToHost, stream));
+    DGRP_HIP(hipStreamSynchronize(stream));
+    return DGRP_OK;
+}
+

@@ -3,6 +3,7 @@
 // -ffp-contract=off: the float32/float64 expressions below must round exactly where the
 // reference's numpy / C code rounds.
 #include "dgrp_common.h"
+#include <vector>
 
 #include <math.h>
 
@@ -448,6 +449,76 @@ static mss_layout mss_carve(void *work, int64_t n)
     l.segs_out = (int32_t *)take(maxruns * 8);
     l.bytes = p - (unsigned char *)work;
     return l;
+}
+
+// Many record bodies of ONE uploaded buffer in a single call: the same three kernels per record, queued back to
+// back, one read-back and one synchronisation for all of them (a file of thousands of short records would
+// otherwise pay an upload and a wait per record).  Record r is the byte range [h_off[r], h_off[r] + h_len[r]) of
+// d_raw; its class indices go to d_idx + h_off[r] (same offsets, capacity h_len[r]); h_info gets 4 values per
+// record as dgrp_fasta_encode defines them.  Workspace: dgrp_fasta_batch_workspace_bytes(nrec, total bytes).
+DGRP_EXPORT int64_t dgrp_fasta_batch_workspace_bytes(int64_t nrec, int64_t total_bytes)
+{
+    if (nrec < 0 || total_bytes < 0) return 0;
+    // per record: the tiles of its own scan (rounded up) + 3 words, and 256 B of counters
+    return dgrp_align_up(((total_bytes + SCAN_TILE - 1) / SCAN_TILE + 4 * nrec + 8) * 8, 256) + nrec * 256 + 256;
+}
+
+DGRP_EXPORT int dgrp_fasta_encode_batch(const uint8_t *d_raw, int64_t nrec, const int64_t *h_off, const int64_t *h_len,
+                                        uint8_t *d_idx, int64_t *h_info, void *d_work, int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(nrec >= 0 && (nrec == 0 || (h_off && h_len && h_info)), "dgrp_fasta_encode_batch: bad arguments");
+    if (nrec == 0) return DGRP_OK;
+    int64_t total = 0;
+    for (int64_t r = 0; r < nrec; ++r) {
+        DGRP_REQUIRE(h_off[r] >= 0 && h_len[r] >= 0, "dgrp_fasta_encode_batch: negative range");
+        total += h_len[r];
+    }
+    DGRP_REQUIRE(total == 0 || (d_raw && d_idx && d_work), "dgrp_fasta_encode_batch: NULL pointer");
+    if (work_bytes < dgrp_fasta_batch_workspace_bytes(nrec, total)) {
+        dgrp_set_error("dgrp_fasta_encode_batch: workspace too small");
+        return DGRP_ENOMEM;
+    }
+    const int64_t tile_words = (total + SCAN_TILE - 1) / SCAN_TILE + 4 * nrec + 8;     // sum of (tiles + 3) per record
+    uint64_t *tiles_base = (uint64_t *)d_work;
+    unsigned long long *gbase = (unsigned long long *)((char *)d_work + dgrp_align_up(tile_words * 8, 256));     // 32 words per record
+    std::vector<unsigned long long> init((size_t)nrec * 32, 0ull);
+    for (int64_t r = 0; r < nrec; ++r) init[(size_t)r * 32 + 1] = 0x7fffffffffffffffull;
+    DGRP_HIP(hipMemcpyAsync(gbase, init.data(), init.size() * 8, hipMemcpyHostToDevice, stream));
+    std::vector<int64_t> grand_at((size_t)nrec, -1);
+    int64_t word = 0;
+    for (int64_t r = 0; r < nrec; ++r) {
+        const int64_t nbytes = h_len[r];
+        if (nbytes == 0) continue;
+        const int64_t ntiles = (nbytes + SCAN_TILE - 1) / SCAN_TILE;
+        uint64_t *tiles = tiles_base + word;
+        uint64_t *grand = tiles + ntiles + 1;
+        grand_at[(size_t)r] = word + ntiles + 1;
+        word += ntiles + 3;
+        unsigned long long *g = gbase + r * 32;
+        const uint8_t *raw = d_raw + h_off[r];
+        hipLaunchKernelGGL(fasta_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, raw, nbytes, tiles, g);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, tiles, ntiles, grand);
+        hipLaunchKernelGGL(fasta_scatter_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, raw, nbytes, tiles,
+                           d_idx + h_off[r], g);
+    }
+    DGRP_LAUNCH_CHECK();
+    std::vector<unsigned long long> hg((size_t)nrec * 32);
+    std::vector<uint64_t> htiles((size_t)(word > 0 ? word : 1));
+    DGRP_HIP(hipMemcpyAsync(hg.data(), gbase, hg.size() * 8, hipMemcpyDeviceToHost, stream));
+    if (word > 0) DGRP_HIP(hipMemcpyAsync(htiles.data(), tiles_base, (size_t)word * 8, hipMemcpyDeviceToHost, stream));
+    DGRP_HIP(hipStreamSynchronize(stream));
+    for (int64_t r = 0; r < nrec; ++r) {
+        int64_t *info = h_info + 4 * r;
+        if (h_len[r] == 0) { info[0] = 1; info[1] = 0; info[2] = 0; info[3] = 0; continue; }
+        const unsigned long long *g = hg.data() + (size_t)r * 32;
+        const int64_t tot = (int64_t)htiles[(size_t)grand_at[(size_t)r]];
+        info[0] = g[0] ? 0 : 1;
+        info[1] = tot;
+        if (g[2] == 0) { info[2] = tot; info[3] = -tot; }
+        else { info[2] = (int64_t)g[1]; info[3] = (int64_t)g[2] - (int64_t)g[1]; }
+    }
+    return DGRP_OK;
 }
 
 DGRP_EXPORT int64_t dgrp_mss_workspace_bytes(int64_t n)

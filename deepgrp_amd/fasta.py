@@ -114,13 +114,15 @@ class DeviceRecord:
         self.startpos, self.d_idx, self.length = startpos, d_idx, length
 
 
-def read_multi_fasta_device(path: Union[str, os.PathLike]):
+def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 256 << 20, group_records: int = 4096):
     """Like read_multi_fasta_file, but plain record bodies are uploaded as raw file bytes and turned
-    into class indices on the GPU (dgrp_fasta_encode: line-end removal, upper-casing, N stripping and
+    into class indices on the GPU (dgrp_fasta_encode_batch: line-end removal, upper-casing, N stripping and
     the class lookup of deepgrp/sequence.pyx in one pass).  Yields (header, DeviceRecord) for those
-    and (header, str) for records that need the reference loop."""
-    import ctypes as C
+    and (header, str) for records that need the reference loop.
 
+    Records are taken in groups (up to `group_bytes` of file or `group_records` records): one upload, the encode
+    kernels of all of them queued back to back, one read-back -- a file of thousands of short records pays one
+    wait per group, not one per record."""
     import numpy as np
     import torch
 
@@ -144,42 +146,58 @@ def read_multi_fasta_device(path: Union[str, os.PathLike]):
         carry_header = ""
         carry_seq: List[str] = []
         try:
-            for a, b in zip(starts[:-1], starts[1:]):
-                nl = mm.find(b"\n", a, b)
-                head_end = b if nl == -1 else nl
-                head = mm[a:head_end]
-                fast = mm[a:a + 1] == b">" and head.isascii()
-                if fast:
-                    body0 = b if nl == -1 else nl + 1
-                    nbytes = b - body0
-                    info = (C.c_int64 * 4)(1, 0, 0, 0)
-                    d_idx = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-                    if nbytes:
-                        d_raw = torch.from_numpy(whole[body0:b]).to(dev)        # numpy view of the mmap: no host copy
-                        wb = L.dgrp_fasta_workspace_bytes(nbytes)
-                        work = torch.empty(wb, dtype=torch.uint8, device=dev)
-                        check(L.dgrp_fasta_encode(d_raw.data_ptr(), nbytes, d_idx.data_ptr(), info, work.data_ptr(), wb,
-                                                  stream_ptr()), "dgrp_fasta_encode")
-                    fast = info[0] == 1
-                if fast:
-                    if carry_header:
-                        yield carry_header, "".join(carry_seq)
-                    carry_header, carry_seq = "", []
-                    header = head.decode("ascii").strip()[1:]
-                    if header:
-                        st, kept = int(info[2]), int(info[3])
-                        yield header, DeviceRecord(st, d_idx[st:st + max(kept, 0)], kept)
-                    continue
-                text = io.TextIOWrapper(io.BytesIO(mm[a:b]), encoding=None, newline=None)
-                for line in text:
-                    line = line.strip()
-                    if line[0] == ">":
+            nchunks = len(starts) - 1
+            c0 = 0
+            while c0 < nchunks:
+                # ---- one group of chunks [c0, c1)
+                c1 = c0 + 1
+                while c1 < nchunks and c1 - c0 < group_records and starts[c1 + 1] - starts[c0] <= group_bytes:
+                    c1 += 1
+                heads, body0s, cand = [], [], []
+                for c in range(c0, c1):
+                    a, b = starts[c], starts[c + 1]
+                    nl = mm.find(b"\n", a, b)
+                    head = mm[a:(b if nl == -1 else nl)]
+                    heads.append(head)
+                    body0s.append(b if nl == -1 else nl + 1)
+                    cand.append(mm[a:a + 1] == b">" and head.isascii())
+                g0, g1 = starts[c0], starts[c1]
+                infos = np.zeros((c1 - c0, 4), np.int64)
+                d_idx = None
+                if any(cand):
+                    d_raw = torch.from_numpy(whole[g0:g1]).to(dev)              # numpy view of the mmap: no host copy
+                    d_idx = torch.empty(g1 - g0, dtype=torch.uint8, device=dev)
+                    off = np.array([body0s[i] - g0 for i in range(c1 - c0)], np.int64)
+                    ln = np.array([(starts[c0 + i + 1] - body0s[i]) if cand[i] else 0 for i in range(c1 - c0)], np.int64)
+                    wb = L.dgrp_fasta_batch_workspace_bytes(c1 - c0, int(ln.sum()))
+                    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+                    check(L.dgrp_fasta_encode_batch(d_raw.data_ptr(), c1 - c0, off.ctypes.data, ln.ctypes.data, d_idx.data_ptr(),
+                                                    infos.ctypes.data, work.data_ptr(), wb, stream_ptr()), "dgrp_fasta_encode_batch")
+                    del d_raw, work
+                for i, c in enumerate(range(c0, c1)):
+                    a, b = starts[c], starts[c + 1]
+                    if cand[i] and infos[i, 0] == 1:
                         if carry_header:
                             yield carry_header, "".join(carry_seq)
-                        carry_header = line[1:]
-                        carry_seq = []
-                    else:
-                        carry_seq.append(line.upper())
+                        carry_header, carry_seq = "", []
+                        header = heads[i].decode("ascii").strip()[1:]
+                        if header:
+                            st, kept = int(infos[i, 2]), int(infos[i, 3])
+                            lo = body0s[i] - g0 + st
+                            yield header, DeviceRecord(st, d_idx[lo:lo + max(kept, 0)], kept)
+                        continue
+                    text = io.TextIOWrapper(io.BytesIO(mm[a:b]), encoding=None, newline=None)
+                    for line in text:
+                        line = line.strip()
+                        if line[0] == ">":
+                            if carry_header:
+                                yield carry_header, "".join(carry_seq)
+                            carry_header = line[1:]
+                            carry_seq = []
+                        else:
+                            carry_seq.append(line.upper())
+                del d_idx
+                c0 = c1
             if carry_header:
                 yield carry_header, "".join(carry_seq)
         finally:

@@ -238,7 +238,29 @@ class ContigPipeline:
         return host.view(SEGMENT_DTYPE).copy()
 
     def run_idx(self, d_idx: torch.Tensor, startpos: int, contig: int = 0) -> np.ndarray:
-        return self.segments(self.labels(self.merged(d_idx)), startpos, contig)
+        """Segment records of one record whose class indices are on the device: one dgrp_predict_record call
+        (the staged merged -> labels -> segments path is kept for callers that time or inspect the stages)."""
+        if self.event_log is not None:
+            return self.segments(self.labels(self.merged(d_idx)), startpos, contig)
+        L = lib()
+        n = d_idx.numel()
+        if n == 0:
+            return np.zeros(0, SEGMENT_DTYPE)
+        dev = d_idx.device
+        wb = L.dgrp_record_workspace_bytes(self.model.handle, n, self.step, int(self.use_mss))
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        cap = max(1024, n // 64)
+        count = C.c_int64(0)
+        while True:
+            rec = torch.empty(cap * SEGMENT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            check(L.dgrp_predict_record(self.model.handle, _ptr(d_idx), n, self.step, self.batch, self.min_mss_len,
+                                        self.xdrop_len, int(self.use_mss), int(startpos), int(contig), _ptr(rec), cap,
+                                        C.byref(count), _ptr(work), wb, stream_ptr()), "dgrp_predict_record")
+            if count.value <= cap:
+                break
+            cap = int(count.value)                          # rare: more segments than guessed, run again
+        host = rec[: count.value * SEGMENT_DTYPE.itemsize].cpu().numpy()
+        return host.view(SEGMENT_DTYPE).copy()
 
     def run(self, sequence, contig: int = 0) -> np.ndarray:
         raw = sequence.encode("utf-8") if isinstance(sequence, str) else bytes(sequence)

@@ -79,6 +79,13 @@ int64_t dgrp_fasta_workspace_bytes(int64_t nbytes);
 int dgrp_fasta_encode(const uint8_t *d_raw, int64_t nbytes, uint8_t *d_idx, int64_t *h_info, void *d_work,
                       int64_t work_bytes, void *stream);
 
+/* The same for nrec record bodies of ONE device buffer in a single call (one read-back, one synchronisation):
+ * record r = bytes [h_off[r], h_off[r] + h_len[r]) of d_raw, its indices go to d_idx + h_off[r], its four info
+ * values to h_info[4 r ..].  For files of many short records. */
+int64_t dgrp_fasta_batch_workspace_bytes(int64_t nrec, int64_t total_bytes);
+int dgrp_fasta_encode_batch(const uint8_t *d_raw, int64_t nrec, const int64_t *h_off, const int64_t *h_len,
+                            uint8_t *d_idx, int64_t *h_info, void *d_work, int64_t work_bytes, void *stream);
+
 /* ---- A3: deepgrp.prediction.fetch_validation_batch (deepgrp/prediction.py:14-37)
  * Number of windows len(range(0, n - T, s)). */
 int64_t dgrp_window_count(int64_t n, int64_t T, int64_t s);
@@ -165,6 +172,18 @@ int64_t dgrp_segments_workspace_bytes(int64_t n);
 int dgrp_segments(const int8_t *d_labels, int64_t n, int64_t offset, int32_t contig,
                   dgrp_segment *d_records, int64_t cap, int64_t *d_count, void *d_work,
                   int64_t work_bytes, void *stream);
+
+/* ---- A3-A11 in one call: everything deepgrp/__main__.py:46-83 and :288-292 do for ONE record whose class indices
+ * (after N stripping, startpos = offset) are in HBM: windows, forward, max-merge with the reference's placement for
+ * `batch`, then scores + MSS labels (use_mss != 0; deepgrp/prediction.py:40-59) or softmax + argmax
+ * (deepgrp/__main__.py:81-83), then the label > 0 segments.  Writes up to cap records to d_records, the total to
+ * *h_count (host; larger than cap means: call again with more room), synchronises the stream.  All intermediates
+ * live in d_work (dgrp_record_workspace_bytes); one host thread per stream may run records concurrently. */
+int64_t dgrp_record_workspace_bytes(const dgrp_model *m, int64_t n, int64_t s, int use_mss);
+int dgrp_predict_record(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch,
+                        int min_mss_len, int xdrop_len, int use_mss, int64_t offset, int32_t contig,
+                        dgrp_segment *d_records, int64_t cap, int64_t *h_count, void *d_work, int64_t work_bytes,
+                        void *stream);
 
 /* ---- N2: evaluation helpers of deepgrp.prediction on label arrays that are already in HBM.
  * deepgrp.prediction.confusion_matrix (deepgrp/prediction.py:204-222): d_cnf int64 [ncls, ncls] (zeroed here),
