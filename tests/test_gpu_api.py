@@ -357,3 +357,105 @@ def test_fasta_device_ingest_matches_reference_loop(orc, tmp_path):
             np.testing.assert_array_equal(idx, orc.encode_idx(ws.encode()[wst:wst + max(wn, 0)]))
         if name in ("plain.fa", "crlf.fa", "alln.fa", "empty_header.fa"):
             assert ndev >= 2, name
+
+
+@pytest.mark.parametrize("group_records", (1, 2, 3, 4096))
+def test_fasta_device_ingest_groups(orc, tmp_path, group_records):
+    """read_multi_fasta_device with small groups (several dgrp_fasta_encode_batch calls, group borders between
+    plain and odd records): identical to the ungrouped result; and dgrp_fasta_encode_batch == dgrp_fasta_encode."""
+    import ctypes as C
+    import torch
+    from deepgrp_amd._lib import check, lib
+    from deepgrp_amd.fasta import DeviceRecord, read_multi_fasta_device, read_multi_fasta_lines
+    from deepgrp_amd.pipeline import require_gpu, stream_ptr
+    rng = np.random.default_rng(8)
+    seq = lambda n: "".join(rng.choice(list("ACGTNacgtn"), size=n))
+    wrap = lambda s, w=60: "\n".join(s[i:i + w] for i in range(0, len(s), w))
+    text = "".join(f">r{k} x\n" + wrap(seq(int(rng.integers(1, 3000)))) + "\n" for k in range(7))
+    text += ">odd\nAC GT\n>onlyheader\n>last\n" + wrap(seq(2049)) + "\n"
+    path = tmp_path / "g.fa"
+    path.write_bytes(text.encode())
+    with open(path) as fh:
+        want = list(read_multi_fasta_lines(fh))
+    got = []
+    for h, rec in read_multi_fasta_device(str(path), group_records=group_records):
+        if isinstance(rec, DeviceRecord):
+            got.append((h, rec.startpos, rec.length, rec.d_idx.cpu().numpy()))
+        else:
+            st, n = orc.strip_n(rec.encode())
+            got.append((h, st, n, orc.encode_idx(rec.encode()[st:st + max(n, 0)])))
+    assert [g[0] for g in got] == [w[0] for w in want]
+    for (h, st, n, idx), (_wh, ws) in zip(got, want):
+        wst, wn = orc.strip_n(ws.encode())
+        assert (st, n) == (wst, wn), h
+        np.testing.assert_array_equal(idx, orc.encode_idx(ws.encode()[wst:wst + max(wn, 0)]))
+    if group_records != 4096:
+        return
+    # the batch entry point against the single-record one on the same bytes
+    dev, L = require_gpu(), lib()
+    raw = np.frombuffer(text.encode(), np.uint8)
+    bodies = [(m.end(), (text.find("\n>", m.end() - 1) + 1) or len(text)) for m in __import__("re").finditer(r"^>[^\n]*\n", text, flags=8)]
+    off = np.array([a for a, _ in bodies], np.int64)
+    ln = np.array([b - a for a, b in bodies], np.int64)
+    d_raw = torch.from_numpy(raw.copy()).to(dev)
+    d_idx = torch.zeros(raw.size, dtype=torch.uint8, device=dev)
+    infos = np.zeros((len(bodies), 4), np.int64)
+    wb = L.dgrp_fasta_batch_workspace_bytes(len(bodies), int(ln.sum()))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    check(L.dgrp_fasta_encode_batch(d_raw.data_ptr(), len(bodies), off.ctypes.data, ln.ctypes.data, d_idx.data_ptr(),
+                                    infos.ctypes.data, work.data_ptr(), wb, stream_ptr()), "batch")
+    for r, (a, b) in enumerate(bodies):
+        one = (C.c_int64 * 4)()
+        d1 = torch.zeros(max(b - a, 1), dtype=torch.uint8, device=dev)
+        w1 = torch.empty(L.dgrp_fasta_workspace_bytes(b - a), dtype=torch.uint8, device=dev)
+        check(L.dgrp_fasta_encode(d_raw.data_ptr() + a, b - a, d1.data_ptr(), one, w1.data_ptr(), w1.numel(), stream_ptr()), "one")
+        assert list(one) == list(infos[r]), r
+        if one[0] == 1:
+            np.testing.assert_array_equal(d1[: one[1]].cpu().numpy(), d_idx[a:a + one[1]].cpu().numpy())
+
+
+@pytest.mark.parametrize("kind", ("gru", "attention", "lstm", "softmax"))
+def test_predict_record_equals_staged_path(orc, kind):
+    """dgrp_predict_record (one call per record) against the staged calls it bundles, incl. a record shorter than a
+    window, the partial-batch placement and the too-small-capacity protocol."""
+    import ctypes as C
+    import torch
+    from deepgrp_amd._lib import check, lib
+    from deepgrp_amd.pipeline import SEGMENT_DTYPE, ContigPipeline, DeviceModel, require_gpu, stream_ptr
+    dev, L = require_gpu(), lib()
+    T, s, B = 40, 7, 9
+    if kind == "lstm":
+        w = orc.LSTMWeights.random(48, 5, T, seed=1, gain=2.0)
+        m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T, rnn="LSTM")
+    else:
+        w = orc.Weights.random(64, 5, T, kind == "attention", seed=2, gain=3.0)
+        m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    rng = np.random.default_rng(5)
+    for n in (1, T - 1, T + 1, 1234, 20011):
+        idx = rng.choice(5, size=n, p=[.24, .25, .25, .24, .02]).astype(np.uint8)
+        d_idx = torch.from_numpy(idx).to(dev)
+        pipe = ContigPipeline(m, s, B, 4, 6, use_mss=kind != "softmax")
+        pipe.event_log = []                                   # staged path
+        want = pipe.run_idx(d_idx, 17, contig=3)
+        pipe.event_log = None                                 # one call
+        got = pipe.run_idx(d_idx, 17, contig=3)
+        assert got.dtype == SEGMENT_DTYPE
+        np.testing.assert_array_equal(got, want)
+        if len(want) > 1:                                     # capacity protocol: count comes back, nothing beyond cap is written
+            wb = L.dgrp_record_workspace_bytes(m.handle, n, s, int(pipe.use_mss))
+            work = torch.empty(wb, dtype=torch.uint8, device=dev)
+            rec = torch.full((2 * SEGMENT_DTYPE.itemsize,), 0xAB, dtype=torch.uint8, device=dev)
+            cnt = C.c_int64()
+            check(L.dgrp_predict_record(m.handle, d_idx.data_ptr(), n, s, B, 4, 6, int(pipe.use_mss), 17, 3, rec.data_ptr(), 1,
+                                        C.byref(cnt), work.data_ptr(), wb, stream_ptr()), "dgrp_predict_record")
+            assert cnt.value == len(want)
+            h = rec.cpu().numpy()
+            np.testing.assert_array_equal(h[:SEGMENT_DTYPE.itemsize].view(SEGMENT_DTYPE), want[:1])
+            assert (h[SEGMENT_DTYPE.itemsize:] == 0xAB).all()
+    with pytest.raises(Exception, match="workspace"):
+        cnt = C.c_int64()
+        work = torch.empty(256, dtype=torch.uint8, device=dev)
+        rec = torch.empty(24 * 8, dtype=torch.uint8, device=dev)
+        check(L.dgrp_predict_record(m.handle, d_idx.data_ptr(), d_idx.numel(), s, B, 4, 6, 1, 0, 0, rec.data_ptr(), 8, C.byref(cnt),
+                                    work.data_ptr(), 256, stream_ptr()), "dgrp_predict_record")
+    m.close()
