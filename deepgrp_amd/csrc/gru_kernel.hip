@@ -783,17 +783,23 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
 // contexts meet once per window in a 6-stage halving butterfly (after stage xor-M a lane keeps the half of the
 // units whose bit M equals its own lane bit) that leaves unit k's total in lane k.
 // ------------------------------------------------------------------------------------------
+// whole-wave reductions without LDS round trips: DPP rotations inside the four 16-lane rows, then the four row
+// results through v_readlane
+__device__ __forceinline__ float lane_value(float x, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l));
+}
 __device__ __forceinline__ float wave_allmax(float x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
-    return x;
+    x = row_allmax(x);
+    const float a = lane_value(x, 0), b = lane_value(x, 16), c = lane_value(x, 32), d = lane_value(x, 48);
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
 __device__ __forceinline__ float wave_allsum(float x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    x = row_allsum(x);
+    const float a = lane_value(x, 0), b = lane_value(x, 16), c = lane_value(x, 32), d = lane_value(x, 48);
+    return (a + b) + (c + d);
 }
 
 template <int UP>
