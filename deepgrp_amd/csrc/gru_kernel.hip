@@ -88,6 +88,12 @@ __device__ __forceinline__ float row_max_ror(float x)
     asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(N));
     return r;
 }
+// exchange inside quads: 0x4E = lanes [2,3,0,1] (xor 2), 0xB1 = [1,0,3,2] (xor 1)
+template <int CTRL>
+__device__ __forceinline__ float quad_perm(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float row_allmax(float x)
 {
     return row_max_ror<1>(row_max_ror<2>(row_max_ror<4>(row_max_ror<8>(x))));
@@ -900,19 +906,49 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
             ctx[k] = c.x; ctx[k + 1] = c.y;
         }
     }
-    // ---- butterfly: lane l ends with the window's context for unit l (and unit l + 64 when CT = 128)
+    // ---- butterfly: lane l ends with the window's context for unit l (and unit l + 64 when CT = 128).
+    // xor 32 / xor 16: v_permlane32_swap / v_permlane16_swap exchange exactly the halves (rows) the two partners
+    // discard, so "kept + received" is one swap and one add; xor 8, 2, 1 are DPP moves; xor 4 has none on gfx9.
 #pragma unroll
     for (int base = 0; base < CT; base += 64) {
 #pragma unroll
-        for (int h = 64; h > 1; h >>= 1) {
-            const int m = h >> 1;                            // partner = lane ^ m, keep the half that matches our bit m
-            const bool up = (lane & m) != 0;
+        for (int j = 0; j < 32; ++j) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ctx[base + j]), __float_as_uint(ctx[base + j + 32]), false, false);
+            ctx[base + j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
 #pragma unroll
-            for (int j = 0; j < m; ++j) {
-                const float keep = up ? ctx[base + j + m] : ctx[base + j];
-                const float send = up ? ctx[base + j] : ctx[base + j + m];
-                ctx[base + j] = keep + __shfl_xor(send, m);
+        for (int j = 0; j < 16; ++j) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(ctx[base + j]), __float_as_uint(ctx[base + j + 16]), false, false);
+            ctx[base + j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        {
+            const bool up = (lane & 8) != 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lo = ctx[base + j] + row_ror<8>(ctx[base + j]), hi = ctx[base + j + 8] + row_ror<8>(ctx[base + j + 8]);
+                ctx[base + j] = up ? hi : lo;
             }
+        }
+        {
+            const bool up = (lane & 4) != 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float keep = up ? ctx[base + j + 4] : ctx[base + j];
+                const float send = up ? ctx[base + j] : ctx[base + j + 4];
+                ctx[base + j] = keep + __shfl_xor(send, 4);
+            }
+        }
+        {
+            const bool up = (lane & 2) != 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float lo = ctx[base + j] + quad_perm<0x4E>(ctx[base + j]), hi = ctx[base + j + 2] + quad_perm<0x4E>(ctx[base + j + 2]);
+                ctx[base + j] = up ? hi : lo;
+            }
+        }
+        {
+            const float lo = ctx[base] + quad_perm<0xB1>(ctx[base]), hi = ctx[base + 1] + quad_perm<0xB1>(ctx[base + 1]);
+            ctx[base] = (lane & 1) ? hi : lo;
         }
     }
     const float inv = __builtin_amdgcn_rcpf(run_l);
