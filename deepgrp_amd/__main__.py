@@ -233,43 +233,47 @@ class CommandLineParser:
                     h0, f0, w0 = pending.popleft()
                     yield h0, f0.result()
 
-        if world == 1:
-            for filename in args.FASTA:
-                _LOG.info("Processing %s", filename)
-                for header, rows in in_order(records_of(filename), run_record):
-                    outstream.write(rows_text(filename, header, rows))
-        else:
-            # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
-            records = []
-            for filename in args.FASTA:
-                for header, rec in records_of(filename):
-                    records.append((filename, header, rec))
-            length = lambda r: r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
-            if getattr(args, "split_contigs", False):
-                from .distributed import merged_split
-                parts = []
-                for i, (_f, _h, rec) in enumerate(records):
-                    if isinstance(rec, DeviceRecord):
-                        if rec.length < 0:
-                            raise ValueError("negative dimensions are not allowed")
-                        startpos, d_idx = rec.startpos, rec.d_idx
-                    else:
-                        startpos, d_idx = upload_sequence(rec.encode("utf-8"))
-                    merged = merged_split(pipe, d_idx)
-                    if rank == 0:
-                        parts.append(pipe.segments(pipe.labels(merged), startpos, i))
-                allrows = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
+        try:
+            if world == 1:
+                for filename in args.FASTA:
+                    _LOG.info("Processing %s", filename)
+                    for header, rows in in_order(records_of(filename), run_record):
+                        outstream.write(rows_text(filename, header, rows))
             else:
-                mine = shard_contigs([length(r[2]) for r in records], world)[rank]
-                parts = [run_record(records[i][2], contig=i) for i in mine]
-                local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
-                allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
-            if rank == 0:
-                for i, (filename, header, _seq) in enumerate(records):
-                    outstream.write(rows_text(filename, header, allrows[allrows["contig"] == i]))
-            dist.barrier()
-        if rank == 0 and args.output != "-":
-            outstream.close()
+                # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
+                records = []
+                for filename in args.FASTA:
+                    for header, rec in records_of(filename):
+                        records.append((filename, header, rec))
+                length = lambda r: r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
+                if getattr(args, "split_contigs", False):
+                    from .distributed import merged_split
+                    parts = []
+                    for i, (_f, _h, rec) in enumerate(records):
+                        if isinstance(rec, DeviceRecord):
+                            if rec.length < 0:
+                                raise ValueError("negative dimensions are not allowed")
+                            startpos, d_idx = rec.startpos, rec.d_idx
+                        else:
+                            startpos, d_idx = upload_sequence(rec.encode("utf-8"))
+                        merged = merged_split(pipe, d_idx)
+                        if rank == 0:
+                            parts.append(pipe.segments(pipe.labels(merged), startpos, i))
+                    allrows = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
+                else:
+                    mine = shard_contigs([length(r[2]) for r in records], world)[rank]
+                    parts = [run_record(records[i][2], contig=i) for i in mine]
+                    local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
+                    allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
+                if rank == 0:
+                    for i, (filename, header, _seq) in enumerate(records):
+                        outstream.write(rows_text(filename, header, allrows[allrows["contig"] == i]))
+                dist.barrier()
+        finally:
+            # rows already produced reach the file even when a later record raises (the reference leaves that to
+            # interpreter shutdown)
+            if rank == 0 and args.output != "-":
+                outstream.close()
 
     @staticmethod
     def train(args: argparse.Namespace, options) -> None:

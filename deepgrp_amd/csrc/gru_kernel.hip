@@ -808,7 +808,7 @@ __device__ __forceinline__ float wave_allsum(float x)
     return (a + b) + (c + d);
 }
 
-template <int UP>
+template <int UP, int CM>
 __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params p)
 {
     constexpr int CT = UP <= 64 ? 64 : 128;                  // context registers per lane (butterfly width)
@@ -967,19 +967,26 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
     const int64_t row0 = p.merge ? dgrp_place_row(p.place, p.w0 + wl, p.s) : wl * (int64_t)T;
     const int off = p.merge && row0 >= lo && row0 - lo + T <= p.ospan ? (int)(row0 - lo) : -1;
     const float *pl = p.pl + wl * (int64_t)T * C;
+    // Straight-line over a compile-time class bound (addresses clamped, surplus classes at -inf): with a runtime
+    // class loop every load sat in its own basic block and was waited for on its own -- five HBM latencies per tile.
+    // The next tile's stored logit halves are requested before this tile's are used.
+    float pn[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) pn[c] = pl[(int64_t)(lane < T ? lane : 0) * C + (c < C ? c : C - 1)];
     for (int t = lane; t < T; t += 64) {
-        float lg[16];
+        float lg[CM];
         float mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c < C) { lg[c] = pl[(int64_t)t * C + c] + ctop[c]; mx = fmaxf(mx, lg[c]); }
+        for (int c = 0; c < CM; ++c) { lg[c] = c < C ? pn[c] + ctop[c] : -INFINITY; mx = fmaxf(mx, lg[c]); }
+        const int tn = t + 64 < T ? t + 64 : t;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) pn[c] = pl[(int64_t)tn * C + (c < C ? c : C - 1)];
         float den = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (c < C) { lg[c] = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg[c] - mx)); den += lg[c]; }
+        for (int c = 0; c < CM; ++c) { lg[c] = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg[c] - mx)); den += lg[c]; }
         const float rden = __builtin_amdgcn_rcpf(den);
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
+        for (int c = 0; c < CM; ++c)
             if (c < C) {
                 const float v = lg[c] * rden;
                 if (!p.merge) p.out[(row0 + t) * C + c] = v;
@@ -1145,12 +1152,17 @@ int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, 
         const size_t dyn = (size_t)p.ospan * m->C * 4;
         static bool configured = false;
         if (!configured) {                                   // static + dynamic LDS may use the whole 160 KiB
-            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (4 * 32 * 8 + 256 * 40 * 2)));
-            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (4 * 64 * 8 + 256 * 72 * 2)));
+            const int d32 = 160 * 1024 - (4 * 32 * 8 + 256 * 40 * 2), d64 = 160 * 1024 - (4 * 64 * 8 + 256 * 72 * 2);
+            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, d32));
+            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, d32));
+            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, d64));
+            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, d64));
             configured = true;
         }
-        if (m->UP == 32) hipLaunchKernelGGL(attention_wave_kernel<32>, dim3(grid), dim3(256), dyn, stream, p);
-        else hipLaunchKernelGGL(attention_wave_kernel<64>, dim3(grid), dim3(256), dyn, stream, p);
+        if (m->UP == 32 && m->C <= 8) hipLaunchKernelGGL((attention_wave_kernel<32, 8>), dim3(grid), dim3(256), dyn, stream, p);
+        else if (m->UP == 32) hipLaunchKernelGGL((attention_wave_kernel<32, 16>), dim3(grid), dim3(256), dyn, stream, p);
+        else if (m->C <= 8) hipLaunchKernelGGL((attention_wave_kernel<64, 8>), dim3(grid), dim3(256), dyn, stream, p);
+        else hipLaunchKernelGGL((attention_wave_kernel<64, 16>), dim3(grid), dim3(256), dyn, stream, p);
         DGRP_LAUNCH_CHECK();
         return DGRP_OK;
     }
