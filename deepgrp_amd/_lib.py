@@ -46,6 +46,8 @@ _SIGNATURES = {
     "dgrp_mss_workspace_bytes": (i64, [i64]),
     "dgrp_mss_labels": (cint, [vp, vp, i64, cint, cint, cint, vp, vp, vp, i64, vp]),
     "dgrp_mss_segments_host": (cint, [vp, i64, vp, i64, C.POINTER(i64)]),
+    "dgrp_mss_batch_workspace_bytes": (i64, [i64, i64]),
+    "dgrp_mss_labels_batch": (cint, [vp, vp, i64, i64, vp, cint, cint, cint, vp, vp, i64, vp]),
     "dgrp_segments_workspace_bytes": (i64, [i64]),
     "dgrp_segments": (cint, [vp, i64, i64, i32, vp, i64, vp, vp, i64, vp]),
     "dgrp_record_workspace_bytes": (i64, [vp, i64, i64, cint]),

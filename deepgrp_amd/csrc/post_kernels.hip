@@ -677,7 +677,7 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                                                       const int32_t *__restrict__ blk_q, const uint8_t *__restrict__ flags,
                                                       const double *__restrict__ sup_sum, const double *__restrict__ sup_abs,
                                                       const int32_t *__restrict__ sup_q, const uint8_t *__restrict__ sup_flags,
-                                                      int have_stats)
+                                                      int have_stats, int independent)
 {
     __shared__ double2 sLR[MSS_LCAP];                           // (L, R)
     __shared__ int4 sIdx[MSS_LCAP];                             // (st, en, pre, -)
@@ -687,7 +687,9 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
     volatile mss_cand *ovf = stack_all + urun[k];               // slots MSS_LCAP.. of this stretch's stack
     int32_t *segs = segs_all + 2 * urun[k];
     int64_t nst = 0, nseg = 0;
-    double cur = k == 0 ? 0.0 : exit_prev[k - 1];               // L outside a run, R inside one
+    // independent: every unit is a record of its own (a batch of records side by side): L starts at 0, the unit
+    // ends with the end-of-sequence flush of mss.c:96, nothing is handed on
+    double cur = (k == 0 || independent) ? 0.0 : exit_prev[k - 1];   // L outside a run, R inside one
     double peak = MSS_NEG;
     bool run_open = false;
     int64_t run_st = 0;
@@ -909,14 +911,14 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
         pos += nvalid;
     }
     if (run_open) close_run(cur, end);
-    if (k == nunits - 1) {
+    if (k == nunits - 1 || independent) {
         flush();
     } else if (nst != 0 || peak != MSS_NEG) {
         if (lane == 0) atomicOr((unsigned long long *)&grand[2], 1ull);   // forced-reset argument failed: caller falls back
     }
     if (lane == 0) {
         segcnt[k] = (uint64_t)nseg;
-        if (pass == 0 || __double_as_longlong(exit_prev[k]) != __double_as_longlong(cur))
+        if (!independent && (pass == 0 || __double_as_longlong(exit_prev[k]) != __double_as_longlong(cur)))
             atomicOr((unsigned long long *)&grand[1], 1ull);
         exit_cur[k] = cur;
     }
@@ -1037,7 +1039,7 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
             hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)nunits), dim3(64), 0, stream, d_scores, l.ustart, l.urun,
                                nunits, l.exitL[(pass + 1) & 1], l.exitL[pass & 1], l.stack, l.segs, l.segcnt, min_sc, xdrop,
                                l.grand, pass, l.blk_sum, l.blk_abs, l.blk_q, l.flags, l.sup_sum, l.sup_abs, l.sup_q,
-                               l.sup_flags, 1);
+                               l.sup_flags, 1, 0);
             DGRP_LAUNCH_CHECK();
             uint64_t g[3] = { 0, 0, 0 };
             DGRP_HIP(hipMemcpyAsync(g, l.grand, 24, hipMemcpyDeviceToHost, stream));
@@ -1148,6 +1150,67 @@ __global__ void __launch_bounds__(256) seg_emit_kernel(const int8_t *__restrict_
 __global__ void seg_total_kernel(const uint64_t *__restrict__ grand, int64_t *__restrict__ count)
 {
     *count = (int64_t)(*grand >> 32);
+}
+
+// ---- A9+A10 for MANY records side by side: record r occupies [h_start[r], h_start[r+1]) of the score / class arrays,
+// every start a multiple of 64; positions between a record's last base and the next start must hold score 0 and
+// class 0 (a non-positive score there closes an open run, may fire an x-drop flush and adds 0 to L: the kept
+// segments are those of the record alone, mss.c:96).  One wave scans one record with the same exact arithmetic as
+// dgrp_mss_labels' single-stretch mode (certified 64-chunks, element-by-element otherwise); one launch of each
+// kernel for all records, one synchronisation.  Meant for records of up to a few 100 kbp.
+DGRP_EXPORT int64_t dgrp_mss_batch_workspace_bytes(int64_t total_n, int64_t nrec)
+{
+    if (total_n < 0 || nrec < 0) return 0;
+    return mss_carve(nullptr, total_n + 4 * nrec + 64).bytes;
+}
+
+DGRP_EXPORT int dgrp_mss_labels_batch(const double *d_scores, const int8_t *d_cls, int64_t total_n, int64_t nrec,
+                                      const int64_t *h_start, int nof_labels, int min_mss_len, int xdrop_len,
+                                      int8_t *d_labels_out, void *d_work, int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(total_n >= 0 && total_n < (1ll << 31) && nrec >= 0 && (nrec == 0 || h_start), "dgrp_mss_labels_batch: bad arguments");
+    DGRP_REQUIRE(nof_labels >= 2 && nof_labels <= 16, "dgrp_mss_labels_batch: nof_labels must be in 2..16");
+    if (nrec == 0 || total_n == 0) return DGRP_OK;
+    DGRP_REQUIRE(d_scores && d_cls && d_labels_out && d_work, "dgrp_mss_labels_batch: NULL pointer");
+    DGRP_REQUIRE(h_start[0] == 0 && h_start[nrec] == total_n, "dgrp_mss_labels_batch: starts must run from 0 to total_n");
+    for (int64_t r = 0; r < nrec; ++r)
+        DGRP_REQUIRE((h_start[r] & 63) == 0 && h_start[r + 1] > h_start[r], "dgrp_mss_labels_batch: record %lld: starts must be increasing multiples of 64", (long long)r);
+    mss_layout l = mss_carve(d_work, total_n + 4 * nrec + 64);
+    if (work_bytes < l.bytes) {
+        dgrp_set_error("dgrp_mss_labels_batch: workspace %lld < %lld bytes", (long long)work_bytes, (long long)l.bytes);
+        return DGRP_ENOMEM;
+    }
+    l.nblk = (total_n + 63) / 64;
+    l.nsup = (l.nblk + 63) / 64;
+    const double s0 = log(0.99 / (1.0 - 0.99));
+    const double xdrop = xdrop_len > 0 ? s0 * xdrop_len * 10.0 : -1;
+    const int min_sc = (int)(s0 * min_mss_len);
+    hipLaunchKernelGGL(mss_blockstat_kernel, dim3((unsigned)((l.nblk + 3) / 4)), dim3(256), 0, stream, d_scores, total_n, l.blk,
+                       l.blk_sum, l.blk_abs, l.blk_q, l.flags);
+    hipLaunchKernelGGL(mss_superstat_kernel, dim3((unsigned)((l.nsup + 3) / 4)), dim3(256), 0, stream, l.blk_sum, l.blk_abs,
+                       l.blk_q, l.flags, l.nblk, l.sup_sum, l.sup_abs, l.sup_q, l.sup_flags);
+    DGRP_LAUNCH_CHECK();
+    std::vector<int64_t> urun((size_t)nrec + 1);
+    for (int64_t r = 0; r <= nrec; ++r) urun[(size_t)r] = h_start[r] / 2 + 2 * r;      // a record of n scores has at most n/2 + 1 runs
+    DGRP_HIP(hipMemcpyAsync(l.ustart, h_start, (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, stream));
+    DGRP_HIP(hipMemcpyAsync(l.urun, urun.data(), (size_t)(nrec + 1) * 8, hipMemcpyHostToDevice, stream));
+    DGRP_HIP(hipMemsetAsync(l.grand, 0, 64, stream));
+    hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)nrec), dim3(64), 0, stream, d_scores, l.ustart, l.urun, nrec, l.exitL[1],
+                       l.exitL[0], l.stack, l.segs, l.segcnt, min_sc, xdrop, l.grand, 0, l.blk_sum, l.blk_abs, l.blk_q, l.flags,
+                       l.sup_sum, l.sup_abs, l.sup_q, l.sup_flags, 1, 1);
+    DGRP_LAUNCH_CHECK();
+    int rc = device_exclusive_scan(l.segcnt, l.segcnt, nrec, l.tiles, l.grand + 3, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(mss_compact_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, stream, l.segs, l.urun, l.segcnt,
+                       l.grand + 3, nrec, l.segs_out);
+    DGRP_LAUNCH_CHECK();
+    DGRP_HIP(hipMemcpyAsync(d_labels_out, d_cls, total_n, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(mss_vote_kernel, dim3(1024), dim3(256), 0, stream, l.segs_out, l.grand + 3, d_cls, nof_labels, d_labels_out);
+    DGRP_LAUNCH_CHECK();
+    // the urun vector must outlive the asynchronous copy
+    DGRP_HIP(hipStreamSynchronize(stream));
+    return DGRP_OK;
 }
 
 DGRP_EXPORT int64_t dgrp_segments_workspace_bytes(int64_t n)

@@ -164,6 +164,16 @@ int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int64_t n, int 
 int dgrp_mss_segments_host(const void *d_work, int64_t work_bytes, int32_t *h_st_en, int64_t cap,
                            int64_t *n_seg);
 
+/* The same for MANY records side by side (files of thousands of short records): record r occupies
+ * [h_start[r], h_start[r+1]) of d_scores / d_cls / d_labels_out, every start a multiple of 64, h_start[nrec] =
+ * total_n < 2^31; positions between a record's last base and the next start must hold score 0.0 and class 0 (they
+ * behave like the end of the sequence, deepgrp/_mss/mss.c:96).  One wave per record, one launch per kernel for all
+ * of them; synchronises the stream. */
+int64_t dgrp_mss_batch_workspace_bytes(int64_t total_n, int64_t nrec);
+int dgrp_mss_labels_batch(const double *d_scores, const int8_t *d_cls, int64_t total_n, int64_t nrec,
+                          const int64_t *h_start, int nof_labels, int min_mss_len, int xdrop_len,
+                          int8_t *d_labels_out, void *d_work, int64_t work_bytes, void *stream);
+
 /* ---- A11: deepgrp.sequence.yield_segments / get_segments (deepgrp/sequence.pyx:38-53,
  * :79-85) filtered by label > 0 (deepgrp/__main__.py:290): run-length extraction with the
  * "last element is its own segment" behaviour.  Writes up to cap records (device) and the total

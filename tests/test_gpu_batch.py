@@ -1,0 +1,60 @@
+"""Batched entry points for files of many short records (dgrp_*_batch): every record of the batch must come out
+exactly as from the per-record path / the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from deepgrp_amd.pipeline import require_gpu
+    return require_gpu()
+
+
+def _scores(rng, n, style):
+    if style == "runs":                         # confident calls in runs, like a trained model
+        lab = np.resize(np.repeat(rng.integers(0, 5, size=n // 40 + 2), rng.integers(1, 120, size=n // 40 + 2)), n)
+        m = np.clip(rng.uniform(0.4, 0.999, n), None, 0.99).astype(np.float32)
+        t = np.abs(np.log(m / (1 - m)))
+        return np.where(lab > 0, t, -10 * t).astype(np.float64), lab.astype(np.int64)
+    if style == "noise":
+        return rng.normal(0, 5, n), rng.integers(0, 5, n).astype(np.int64)
+    s = rng.integers(-6, 7, n).astype(np.float64) * 0.5   # small integers: zeros, ties, exact sums
+    return s, rng.integers(0, 3, n).astype(np.int64)
+
+
+@pytest.mark.parametrize("style", ("runs", "noise", "ints"))
+@pytest.mark.parametrize("ml,xd", [(50, 50), (3, 10), (10, 0), (0, -1)])
+def test_mss_labels_batch_vs_oracle(dev, orc, style, ml, xd):
+    import torch
+    from deepgrp_amd._lib import check, lib
+    from deepgrp_amd.pipeline import stream_ptr
+    L = lib()
+    rng = np.random.default_rng(hash((style, ml, xd)) % 2**32)
+    lens = [1, 2, 63, 64, 65, 128, 129, 1000, 4097, 20000, 7, 300] + [int(x) for x in rng.integers(1, 3000, 40)]
+    starts = np.zeros(len(lens) + 1, np.int64)
+    for i, n in enumerate(lens):
+        starts[i + 1] = starts[i] + (n + 63) // 64 * 64
+    total = int(starts[-1])
+    S = np.zeros(total, np.float64)
+    cls = np.zeros(total, np.int8)
+    want = np.zeros(total, np.int8)
+    for i, n in enumerate(lens):
+        s, lab = _scores(rng, n, style)
+        a = int(starts[i])
+        S[a:a + n] = s
+        cls[a:a + n] = lab
+        want[a:a + n] = orc.find_mss_labels(s, lab, 5, ml, xd)
+    d_S, d_cls = torch.from_numpy(S).to(dev), torch.from_numpy(cls).to(dev)
+    d_out = torch.empty(total, dtype=torch.int8, device=dev)
+    wb = L.dgrp_mss_batch_workspace_bytes(total, len(lens))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    check(L.dgrp_mss_labels_batch(d_S.data_ptr(), d_cls.data_ptr(), total, len(lens), starts.ctypes.data, 5, ml, xd,
+                                  d_out.data_ptr(), work.data_ptr(), wb, stream_ptr()), "dgrp_mss_labels_batch")
+    got = d_out.cpu().numpy()
+    for i, n in enumerate(lens):
+        a = int(starts[i])
+        np.testing.assert_array_equal(got[a:a + n], want[a:a + n], err_msg=f"record {i} n={n}")
