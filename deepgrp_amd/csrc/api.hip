@@ -434,3 +434,116 @@ DGRP_EXPORT int dgrp_predict_record(const dgrp_model *m, const uint8_t *d_idx, i
     return DGRP_OK;
 }
 
+// ---- the same for a BATCH of short records in a handful of launches (files of thousands of contigs) -------------
+// (post_kernels.hip)
+int dgrp_batch_marks(const int64_t *d_start, const int64_t *d_len, int64_t nrec, int64_t total_n, uint8_t *d_marks,
+                     double *d_scores, int8_t *d_cls, hipStream_t stream);
+int dgrp_batch_segments(const int8_t *d_labels, const uint8_t *d_marks, int64_t total_n, const int64_t *d_start, int64_t nrec,
+                        const int64_t *d_startpos, const int32_t *d_contig, dgrp_segment *d_records, int64_t cap,
+                        int64_t *d_count, void *d_work, int64_t work_bytes, hipStream_t stream);
+
+struct batch_layout {
+    int64_t out, scores, cls, labels, marks, count, recs, wgf, start, len, spos, contig, post, post_bytes, bytes;
+};
+
+static batch_layout batch_carve(const dgrp_model *m, int64_t nrec, int64_t total_rows)
+{
+    batch_layout l;
+    int64_t p = 0;
+    auto take = [&](int64_t b) { const int64_t q = p; p += dgrp_align_up(b, 256); return q; };
+    l.out = take(total_rows * m->C * 4);
+    l.scores = take(total_rows * 8);
+    l.cls = take(total_rows);
+    l.labels = take(total_rows);
+    l.marks = take(total_rows);
+    l.count = take(8);
+    l.recs = take(nrec * 64);
+    l.wgf = take((nrec + 1) * 8);
+    l.start = take((nrec + 1) * 8);
+    l.len = take(nrec * 8);
+    l.spos = take(nrec * 8);
+    l.contig = take(nrec * 4);
+    l.post_bytes = std::max<int64_t>(std::max<int64_t>(dgrp_mss_batch_workspace_bytes(total_rows, nrec), dgrp_segments_workspace_bytes(total_rows)), 4096);
+    l.post = take(l.post_bytes);
+    l.bytes = p;
+    return l;
+}
+
+static int64_t batch_rows(int64_t nrec, const int64_t *h_n)
+{
+    int64_t rows = 0;
+    for (int64_t r = 0; r < nrec; ++r) rows += dgrp_align_up(h_n[r], 64);
+    return rows;
+}
+
+DGRP_EXPORT int64_t dgrp_batch_workspace_bytes(const dgrp_model *m, int64_t nrec, const int64_t *h_n)
+{
+    if (!m || nrec < 0 || (nrec > 0 && !h_n)) return 0;
+    for (int64_t r = 0; r < nrec; ++r)
+        if (h_n[r] < 1) return 0;
+    return batch_carve(m, nrec, batch_rows(nrec, h_n)).bytes;
+}
+
+DGRP_EXPORT int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t nrec, const int64_t *h_idx_off,
+                                   const int64_t *h_n, const int64_t *h_startpos, const int32_t *h_contig, int64_t s,
+                                   int64_t batch, int min_mss_len, int xdrop_len, dgrp_segment *d_records, int64_t cap,
+                                   int64_t *h_count, void *d_work, int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(m && nrec >= 0 && s >= 1 && batch >= 1 && cap >= 0 && h_count, "dgrp_predict_batch: bad arguments");
+    *h_count = 0;
+    if (nrec == 0) return DGRP_OK;
+    DGRP_REQUIRE(m->cell == 0 && !m->attention, "dgrp_predict_batch: GRU models without attention only (use dgrp_predict_record)");
+    DGRP_REQUIRE(d_idx && h_idx_off && h_n && h_startpos && h_contig && d_work && (cap == 0 || d_records), "dgrp_predict_batch: NULL pointer");
+    for (int64_t r = 0; r < nrec; ++r)
+        DGRP_REQUIRE(h_n[r] >= 1 && h_idx_off[r] >= 0, "dgrp_predict_batch: record %lld: empty records do not belong in a batch", (long long)r);
+    const int64_t rows = batch_rows(nrec, h_n);
+    DGRP_REQUIRE(rows < (1ll << 31), "dgrp_predict_batch: %lld rows in one batch (limit 2^31)", (long long)rows);
+    const batch_layout l = batch_carve(m, nrec, rows);
+    if (work_bytes < l.bytes) {
+        dgrp_set_error("dgrp_predict_batch: workspace %lld < %lld bytes", (long long)work_bytes, (long long)l.bytes);
+        return DGRP_ENOMEM;
+    }
+    char *w = (char *)d_work;
+    // ---- tables
+    std::vector<int64_t> recs((size_t)nrec * 8, 0), wgf((size_t)nrec + 1, 0), start((size_t)nrec + 1, 0);
+    for (int64_t r = 0; r < nrec; ++r) {
+        const int64_t nwin = dgrp_window_count(h_n[r], m->T, s);
+        const dgrp_placement pl = dgrp_make_placement(nwin, batch);
+        int64_t *e = recs.data() + (size_t)r * 8;
+        e[0] = h_idx_off[r]; e[1] = h_n[r]; e[2] = start[(size_t)r]; e[3] = nwin; e[4] = pl.nfullB; e[5] = pl.shift;
+        wgf[(size_t)r + 1] = wgf[(size_t)r] + (nwin + 15) / 16;
+        start[(size_t)r + 1] = start[(size_t)r] + dgrp_align_up(h_n[r], 64);
+    }
+    DGRP_HIP(hipMemcpyAsync(w + l.recs, recs.data(), recs.size() * 8, hipMemcpyHostToDevice, stream));
+    DGRP_HIP(hipMemcpyAsync(w + l.wgf, wgf.data(), wgf.size() * 8, hipMemcpyHostToDevice, stream));
+    DGRP_HIP(hipMemcpyAsync(w + l.start, start.data(), start.size() * 8, hipMemcpyHostToDevice, stream));
+    DGRP_HIP(hipMemcpyAsync(w + l.len, h_n, (size_t)nrec * 8, hipMemcpyHostToDevice, stream));
+    DGRP_HIP(hipMemcpyAsync(w + l.spos, h_startpos, (size_t)nrec * 8, hipMemcpyHostToDevice, stream));
+    DGRP_HIP(hipMemcpyAsync(w + l.contig, h_contig, (size_t)nrec * 4, hipMemcpyHostToDevice, stream));
+    // ---- A3-A6 for all records: one launch
+    float *out = (float *)(w + l.out);
+    DGRP_HIP(hipMemsetAsync(out, 0, (size_t)rows * m->C * 4, stream));
+    int rc = dgrp_gru_launch_batch(m, d_idx, s, w + l.recs, (const int64_t *)(w + l.wgf), nrec, wgf[(size_t)nrec], out, stream);
+    if (rc) return rc;
+    // ---- A7: scores over all rows, then padding rows to (0.0, class 0) and the record marks
+    double *scores = (double *)(w + l.scores);
+    int8_t *cls = (int8_t *)(w + l.cls), *labels = (int8_t *)(w + l.labels);
+    uint8_t *marks = (uint8_t *)(w + l.marks);
+    rc = dgrp_scores(out, rows, m->C, scores, cls, stream);
+    if (rc) return rc;
+    rc = dgrp_batch_marks((const int64_t *)(w + l.start), (const int64_t *)(w + l.len), nrec, rows, marks, scores, cls, stream);
+    if (rc) return rc;
+    // ---- A9+A10 (synchronises: the host tables above are safe to drop afterwards)
+    rc = dgrp_mss_labels_batch(scores, cls, rows, nrec, start.data(), m->C, min_mss_len, xdrop_len, labels, w + l.post, l.post_bytes, stream);
+    if (rc) return rc;
+    // ---- A11
+    int64_t *d_count = (int64_t *)(w + l.count);
+    rc = dgrp_batch_segments(labels, marks, rows, (const int64_t *)(w + l.start), nrec, (const int64_t *)(w + l.spos),
+                             (const int32_t *)(w + l.contig), d_records, cap, d_count, w + l.post, l.post_bytes, stream);
+    if (rc) return rc;
+    DGRP_HIP(hipMemcpyAsync(h_count, d_count, 8, hipMemcpyDeviceToHost, stream));
+    DGRP_HIP(hipStreamSynchronize(stream));
+    return DGRP_OK;
+}
+

@@ -43,6 +43,12 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
 #define DGRP_WG_WINDOWS 16
 
+struct gru_rec {
+    int64_t idx_off, n, out_row, nwin;
+    dgrp_placement place;
+    int64_t pad_[2];
+};
+
 struct gru_params {
     const uint8_t *idx;   // class index per base [n]
     int64_t n, s, w0, nw; // this launch covers windows w0 .. w0+nw-1 (absolute indices)
@@ -55,6 +61,11 @@ struct gru_params {
     int Tp;               // T rounded up to 16 (row pitch of the staged sequences)
     int ospan;            // rows of the LDS output image (mode 0), 0 = none
     uint64_t *stamps;
+    // batched records (mode 0): workgroup b belongs to record r with wg_first[r] <= b < wg_first[r+1]; idx / out / n /
+    // placement then come from recs[r] and windows count from 0 inside the record
+    const struct gru_rec *recs;
+    const int64_t *wg_first;
+    int64_t nrec;
 };
 
 // The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
@@ -132,8 +143,26 @@ __host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 
 #define DGRP_PIPE 1
 #endif
 template <int NW, int MODE, bool ONERCP>
-__global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params p)
+__global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params pin)
 {
+    gru_params p = pin;
+    int64_t bid = blockIdx.x;
+    if (MODE == 0 && pin.recs) {
+        // which record: last r with wg_first[r] <= blockIdx.x (uniform over the workgroup: scalar loads)
+        int64_t lo_r = 0, hi_r = pin.nrec;
+        while (hi_r - lo_r > 1) {
+            const int64_t mid = (lo_r + hi_r) >> 1;
+            if (pin.wg_first[mid] <= (int64_t)blockIdx.x) lo_r = mid; else hi_r = mid;
+        }
+        const gru_rec rc = pin.recs[lo_r];
+        bid = (int64_t)blockIdx.x - pin.wg_first[lo_r];
+        p.idx = pin.idx + rc.idx_off;
+        p.n = rc.n;
+        p.out = pin.out + rc.out_row * pin.C;
+        p.place = rc.place;
+        p.w0 = 0;
+        p.nw = rc.nwin;
+    }
     constexpr bool PIPE = DGRP_PIPE;
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;   // HS: padded row pitch (halves) -> conflict-free b128 reads
     // u > 128: the three gate slices no longer fit 256 VGPRs; the z gate's fragments (needed last in a
@@ -155,7 +184,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, C = p.C;
-    const int64_t wg_w = p.w0 + (int64_t)blockIdx.x * DGRP_WG_WINDOWS;   // first window of this workgroup
+    const int64_t wg_w = p.w0 + bid * DGRP_WG_WINDOWS;                  // first window of this workgroup
     const int nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - wg_w);
 
     // ---- resident B fragments ------------------------------------------------------------
@@ -1067,6 +1096,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = mode;
     p.Tp = (int)dgrp_align_up(m->T, 16);
     p.stamps = nullptr;
+    p.recs = nullptr; p.wg_first = nullptr; p.nrec = 0;
 #ifdef DGRP_STAMP
     static uint64_t *d_stamps = nullptr;
     const int64_t ngroups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
@@ -1124,6 +1154,39 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     default:
         dgrp_set_error("units=%d not supported by the GRU kernel (max 256)", m->u);
         return DGRP_EINVAL;
+    }
+}
+
+// GRU forward + merge for a batch of records in ONE launch (mode 0, no attention): the record table and the
+// cumulative workgroup counts are device arrays prepared by the caller (api.hip: dgrp_predict_batch)
+int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, const void *d_recs, const int64_t *d_wg_first,
+                          int64_t nrec, int64_t total_groups, float *d_out, hipStream_t stream)
+{
+    if (nrec <= 0 || total_groups <= 0) return DGRP_OK;
+    DGRP_REQUIRE(m->cell == 0 && !m->attention && m->NW <= 8, "dgrp_gru_launch_batch: GRU models without attention only");
+    gru_params p;
+    p.idx = d_idx; p.n = 0; p.s = s; p.w0 = 0; p.nw = 0; p.place = dgrp_placement{ 0, 0 };
+    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = nullptr;
+    p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = 0;
+    p.Tp = (int)dgrp_align_up(m->T, 16);
+    p.stamps = nullptr;
+    p.recs = (const gru_rec *)d_recs; p.wg_first = d_wg_first; p.nrec = nrec;
+    const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
+    const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
+    const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed) / (m->C * 4);
+    p.ospan = (int)(want < cap ? want : cap);
+    if (p.ospan < m->T) p.ospan = 0;
+    const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
+    DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
+    switch (m->NW) {
+    case 1: return launch_gru<1>(p, total_groups, lds, m->onercp != 0, stream);
+    case 2: return launch_gru<2>(p, total_groups, lds, m->onercp != 0, stream);
+    case 3: return launch_gru<3>(p, total_groups, lds, m->onercp != 0, stream);
+    case 4: return launch_gru<4>(p, total_groups, lds, m->onercp != 0, stream);
+    case 5: return launch_gru<5>(p, total_groups, lds, m->onercp != 0, stream);
+    case 6: return launch_gru<6>(p, total_groups, lds, m->onercp != 0, stream);
+    case 7: return launch_gru<7>(p, total_groups, lds, m->onercp != 0, stream);
+    default: return launch_gru<8>(p, total_groups, lds, m->onercp != 0, stream);
     }
 }
 

@@ -1213,6 +1213,126 @@ DGRP_EXPORT int dgrp_mss_labels_batch(const double *d_scores, const int8_t *d_cl
     return DGRP_OK;
 }
 
+// ---- batched records: padding fix-up of the score transform and the run-length extraction -----------------------
+// marks: bit0 first base of a record, bit1 its last base, bit2 its second-to-last base, bit3 padding
+__global__ void __launch_bounds__(64) rec_marks_kernel(const int64_t *__restrict__ start, const int64_t *__restrict__ len,
+                                                       int64_t nrec, uint8_t *__restrict__ marks, double *__restrict__ scores,
+                                                       int8_t *__restrict__ cls)
+{
+    const int64_t r = blockIdx.x;
+    if (r >= nrec) return;
+    const int64_t a = start[r], n = len[r], b = start[r + 1];
+    if (threadIdx.x == 0) {
+        // (atomicOr on the containing word would be needed if two marks of one record could share a byte: they cannot)
+        uint8_t m0 = 1;
+        if (n == 1) m0 |= 2;
+        if (n == 2) m0 |= 4;
+        marks[a] = m0;
+        if (n >= 2) marks[a + n - 1] = (uint8_t)(2 | (n == 1 ? 1 : 0));
+        if (n >= 3) marks[a + n - 2] = 4;
+    }
+    for (int64_t i = a + n + threadIdx.x; i < b; i += 64) {
+        marks[i] = 8;
+        if (scores) scores[i] = 0.0;
+        if (cls) cls[i] = 0;
+    }
+}
+
+__device__ __forceinline__ uint64_t seg_flags_batch(const int8_t *lab, const uint8_t *marks, int64_t i)
+{
+    const uint8_t m = marks[i];
+    const int8_t v = lab[i];
+    if ((m & 8) || v == 0) return 0;
+    // sequence.pyx:43-53 per record: the last base is always its own segment
+    const bool st = (m & 1) || (m & 2) || lab[i - 1] != v;
+    const bool en = (m & 2) || (m & 4) || lab[i + 1] != v;
+    return ((uint64_t)st << 32) + (uint64_t)en;
+}
+
+__global__ void __launch_bounds__(256) seg_batch_count_kernel(const int8_t *__restrict__ lab, const uint8_t *__restrict__ marks,
+                                                              int64_t n, uint64_t *__restrict__ tilecnt)
+{
+    __shared__ uint64_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    uint64_t c = 0;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + j * 256 + threadIdx.x;
+        if (i < n) c += seg_flags_batch(lab, marks, i);
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ void __launch_bounds__(256) seg_batch_emit_kernel(const int8_t *__restrict__ lab, const uint8_t *__restrict__ marks,
+                                                             int64_t n, const int64_t *__restrict__ start, int64_t nrec,
+                                                             const int64_t *__restrict__ startpos, const int32_t *__restrict__ contig,
+                                                             const uint64_t *__restrict__ tileoff, dgrp_segment *__restrict__ rec,
+                                                             int64_t cap)
+{
+    __shared__ uint64_t lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
+    uint64_t f[8], s = 0;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + j;
+        f[j] = i < n ? seg_flags_batch(lab, marks, i) : 0;
+        s += f[j];
+    }
+    uint64_t ex = block_exclusive_scan(s, nullptr, lds) + tileoff[blockIdx.x];
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + j;
+        if (f[j]) {
+            // the record of position i: last r with start[r] <= i
+            int64_t lo = 0, hi = nrec;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (start[mid] <= i) lo = mid; else hi = mid;
+            }
+            const int64_t off = startpos[lo] - start[lo];
+            if (f[j] >> 32) {
+                const int64_t k = (int64_t)(ex >> 32);
+                if (k < cap) { rec[k].start = i + off; rec[k].label = lab[i]; rec[k].contig = contig[lo]; }
+            }
+            if (f[j] & 1) {
+                const int64_t k = (int64_t)(ex & 0xffffffffull);
+                if (k < cap) rec[k].end = i + 1 + off;
+            }
+        }
+        ex += f[j];
+    }
+}
+
+// internal (api.hip: dgrp_predict_batch): marks + zeroed padding, then the segments of all records in position order
+int dgrp_batch_marks(const int64_t *d_start, const int64_t *d_len, int64_t nrec, int64_t total_n, uint8_t *d_marks,
+                     double *d_scores, int8_t *d_cls, hipStream_t stream)
+{
+    DGRP_HIP(hipMemsetAsync(d_marks, 0, (size_t)total_n, stream));
+    hipLaunchKernelGGL(rec_marks_kernel, dim3((unsigned)nrec), dim3(64), 0, stream, d_start, d_len, nrec, d_marks, d_scores, d_cls);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
+int dgrp_batch_segments(const int8_t *d_labels, const uint8_t *d_marks, int64_t total_n, const int64_t *d_start, int64_t nrec,
+                        const int64_t *d_startpos, const int32_t *d_contig, dgrp_segment *d_records, int64_t cap,
+                        int64_t *d_count, void *d_work, int64_t work_bytes, hipStream_t stream)
+{
+    if (work_bytes < dgrp_segments_workspace_bytes(total_n)) {
+        dgrp_set_error("dgrp_batch_segments: workspace too small");
+        return DGRP_ENOMEM;
+    }
+    const int64_t ntiles = (total_n + SCAN_TILE - 1) / SCAN_TILE;
+    uint64_t *tiles = (uint64_t *)d_work;
+    uint64_t *grand = tiles + ntiles + 1;
+    hipLaunchKernelGGL(seg_batch_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, d_marks, total_n, tiles);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, tiles, ntiles, grand);
+    hipLaunchKernelGGL(seg_batch_emit_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, d_marks, total_n, d_start,
+                       nrec, d_startpos, d_contig, tiles, d_records, cap);
+    hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1), 0, stream, grand, d_count);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
 DGRP_EXPORT int64_t dgrp_segments_workspace_bytes(int64_t n)
 {
     if (n < 0) return 0;

@@ -262,6 +262,39 @@ class ContigPipeline:
         host = rec[: count.value * SEGMENT_DTYPE.itemsize].cpu().numpy()
         return host.view(SEGMENT_DTYPE).copy()
 
+    def batchable(self) -> bool:
+        """dgrp_predict_batch covers GRU models without attention on the MSS path."""
+        return self.use_mss and not self.model.attention and getattr(self.model, "rnn", "GRU") == "GRU" and self.event_log is None
+
+    def run_batch(self, d_base: torch.Tensor, offsets, lengths, startposes, contigs) -> np.ndarray:
+        """Segment records of MANY short records whose class indices lie in one device buffer (record r: `lengths[r]`
+        >= 1 indices at `d_base[offsets[r]:]`): one dgrp_predict_batch call.  Rows come back in record order."""
+        L = lib()
+        nrec = len(lengths)
+        if nrec == 0:
+            return np.zeros(0, SEGMENT_DTYPE)
+        off = np.ascontiguousarray(offsets, np.int64)
+        ln = np.ascontiguousarray(lengths, np.int64)
+        sp = np.ascontiguousarray(startposes, np.int64)
+        cg = np.ascontiguousarray(contigs, np.int32)
+        dev = d_base.device
+        wb = L.dgrp_batch_workspace_bytes(self.model.handle, nrec, ln.ctypes.data)
+        if wb <= 0:
+            raise ValueError("run_batch: every record of a batch needs at least one base")
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        cap = max(1024, int(ln.sum()) // 64 + 2 * nrec)
+        count = C.c_int64(0)
+        while True:
+            rec = torch.empty(cap * SEGMENT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            check(L.dgrp_predict_batch(self.model.handle, _ptr(d_base), nrec, off.ctypes.data, ln.ctypes.data, sp.ctypes.data,
+                                       cg.ctypes.data, self.step, self.batch, self.min_mss_len, self.xdrop_len, _ptr(rec), cap,
+                                       C.byref(count), _ptr(work), wb, stream_ptr()), "dgrp_predict_batch")
+            if count.value <= cap:
+                break
+            cap = int(count.value)
+        host = rec[: count.value * SEGMENT_DTYPE.itemsize].cpu().numpy()
+        return host.view(SEGMENT_DTYPE).copy()
+
     def run(self, sequence, contig: int = 0) -> np.ndarray:
         raw = sequence.encode("utf-8") if isinstance(sequence, str) else bytes(sequence)
         startpos, d_idx = upload_sequence(raw)

@@ -195,6 +195,19 @@ int dgrp_predict_record(const dgrp_model *m, const uint8_t *d_idx, int64_t n, in
                         dgrp_segment *d_records, int64_t cap, int64_t *h_count, void *d_work, int64_t work_bytes,
                         void *stream);
 
+/* The same chain for a BATCH of short records in a handful of launches (a file of thousands of contigs): record r =
+ * h_n[r] >= 1 class indices at d_idx + h_idx_off[r] (after N stripping, startpos h_startpos[r]); GRU models without
+ * attention, MSS labels (the -m path and the other models go record by record).  One GRU launch covers the windows
+ * of all records, the post-processing runs on the records laid side by side (64-aligned), one wave per record in
+ * the MSS scan.  d_records receives the segments of all records in record order, then position order, `contig` =
+ * h_contig[r]; *h_count as in dgrp_predict_record.  Synchronises the stream.  Rows (each record rounded up to 64)
+ * must stay below 2^31. */
+int64_t dgrp_batch_workspace_bytes(const dgrp_model *m, int64_t nrec, const int64_t *h_n);
+int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t nrec, const int64_t *h_idx_off,
+                       const int64_t *h_n, const int64_t *h_startpos, const int32_t *h_contig, int64_t s, int64_t batch,
+                       int min_mss_len, int xdrop_len, dgrp_segment *d_records, int64_t cap, int64_t *h_count,
+                       void *d_work, int64_t work_bytes, void *stream);
+
 /* ---- N2: evaluation helpers of deepgrp.prediction on label arrays that are already in HBM.
  * deepgrp.prediction.confusion_matrix (deepgrp/prediction.py:204-222): d_cnf int64 [ncls, ncls] (zeroed here),
  * cnf[true, pred] += 1 per base; labels int8 in [0, ncls), ncls <= 16, arrays 16-byte aligned.  *d_bad (device

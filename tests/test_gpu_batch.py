@@ -58,3 +58,32 @@ def test_mss_labels_batch_vs_oracle(dev, orc, style, ml, xd):
     for i, n in enumerate(lens):
         a = int(starts[i])
         np.testing.assert_array_equal(got[a:a + n], want[a:a + n], err_msg=f"record {i} n={n}")
+
+
+@pytest.mark.parametrize("u,T,s,B", [(128, 200, 50, 256), (64, 40, 7, 9), (32, 30, 4, 7), (160, 50, 10, 16)])
+def test_predict_batch_equals_record_by_record(dev, orc, u, T, s, B):
+    """dgrp_predict_batch (one GRU launch, batched post-processing) against dgrp_predict_record per record: identical
+    segment rows -- incl. records shorter than a window, of exactly one window, 64-aligned lengths and the
+    partial-batch placement."""
+    import torch
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel
+    w = orc.Weights.random(u, 5, T, False, seed=u, gain=3.0)
+    m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T)
+    rng = np.random.default_rng(u + T)
+    lens = [1, 2, T - 1, T, T + 1, 64, 128, T + s, T + 16 * s, 3 * T + 7, 4097] + [int(x) for x in rng.integers(1, 6000, 30)]
+    gaps = rng.integers(0, 37, len(lens))                     # records sit at arbitrary byte offsets of the buffer
+    offs, pos = [], 0
+    for n, g in zip(lens, gaps):
+        pos += int(g)
+        offs.append(pos)
+        pos += n
+    base = rng.choice(5, size=pos + 5, p=[.24, .25, .25, .24, .02]).astype(np.uint8)
+    d_base = torch.from_numpy(base).to(dev)
+    pipe = ContigPipeline(m, s, B, 4, 6)
+    assert pipe.batchable()
+    sp = [int(x) for x in rng.integers(0, 1000, len(lens))]
+    got = pipe.run_batch(d_base, offs, lens, sp, list(range(len(lens))))
+    want = np.concatenate([pipe.run_idx(d_base[o:o + n].clone(), p0, contig=i) for i, (o, n, p0) in enumerate(zip(offs, lens, sp))])
+    np.testing.assert_array_equal(got, want)
+    assert len(want) > len(lens)
+    m.close()
