@@ -216,7 +216,10 @@ class CommandLineParser:
                     local.stream.synchronize()
                 return out
 
-            size = lambda r: r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
+            def size(r):
+                if isinstance(r, list):
+                    return sum(x.length for _h, x in r)
+                return r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
             pending: "collections.deque" = collections.deque()
             inflight = 0
             with ThreadPoolExecutor(max_workers=workers) as pool:
@@ -233,12 +236,51 @@ class CommandLineParser:
                     h0, f0, w0 = pending.popleft()
                     yield h0, f0.result()
 
+        SMALL, BATCH_RECORDS, BATCH_BASES = 1 << 18, 4096, 64 << 20
+
+        def work_items(records):
+            """Consecutive short records of one ingest buffer become one item (a list), everything else stays single:
+            a batch goes through dgrp_predict_batch -- a handful of launches for thousands of records."""
+            group, bases = [], 0
+
+            def flush():
+                nonlocal group, bases
+                if group:
+                    yield "batch", group
+                group, bases = [], 0
+
+            for header, rec in records:
+                small = (pipe.batchable() and isinstance(rec, DeviceRecord) and rec.base is not None and 1 <= rec.length <= SMALL)
+                if small and group and (group[0][1].base is not rec.base or len(group) >= BATCH_RECORDS or bases + rec.length > BATCH_BASES):
+                    yield from flush()
+                if small:
+                    group.append((header, rec))
+                    bases += rec.length
+                else:
+                    yield from flush()
+                    yield header, rec
+            yield from flush()
+
+        def run_item(item):
+            if isinstance(item, list):                        # a batch: rows of all its records, split per record afterwards
+                base = item[0][1].base
+                rows = pipe.run_batch(base, [r.offset for _h, r in item], [r.length for _h, r in item],
+                                      [r.startpos for _h, r in item], list(range(len(item))))
+                cuts = np.searchsorted(rows["contig"], np.arange(len(item) + 1))
+                return [h for h, _r in item], [rows[cuts[i]:cuts[i + 1]] for i in range(len(item))]
+            return run_record(item)
+
         try:
             if world == 1:
                 for filename in args.FASTA:
                     _LOG.info("Processing %s", filename)
-                    for header, rows in in_order(records_of(filename), run_record):
-                        outstream.write(rows_text(filename, header, rows))
+                    for key, result in in_order(work_items(records_of(filename)), run_item):
+                        if key == "batch":
+                            headers, parts = result
+                            for header, rows in zip(headers, parts):
+                                outstream.write(rows_text(filename, header, rows))
+                        else:
+                            outstream.write(rows_text(filename, key, result))
             else:
                 # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
                 records = []

@@ -108,10 +108,12 @@ class DeviceRecord:
     """A record whose sequence never existed as a Python string: class indices in HBM.
     `d_idx` is the kept part (leading/trailing N dropped), `startpos` the number of leading N."""
 
-    __slots__ = ("startpos", "d_idx", "length")
+    __slots__ = ("startpos", "d_idx", "length", "base", "offset")
 
-    def __init__(self, startpos, d_idx, length):
+    def __init__(self, startpos, d_idx, length, base=None, offset=0):
         self.startpos, self.d_idx, self.length = startpos, d_idx, length
+        # the ingest group's buffer and the position of d_idx in it: records of one group can go to the GPU as a batch
+        self.base, self.offset = base, offset
 
 
 def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 256 << 20, group_records: int = 4096):
@@ -184,7 +186,7 @@ def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 25
                         if header:
                             st, kept = int(infos[i, 2]), int(infos[i, 3])
                             lo = body0s[i] - g0 + st
-                            yield header, DeviceRecord(st, d_idx[lo:lo + max(kept, 0)], kept)
+                            yield header, DeviceRecord(st, d_idx[lo:lo + max(kept, 0)], kept, d_idx, lo)
                         continue
                     text = io.TextIOWrapper(io.BytesIO(mm[a:b]), encoding=None, newline=None)
                     for line in text:

@@ -265,6 +265,31 @@ def test_cli_many_records_ordered_and_errors_in_place(orc, tmp_path):
     assert out2.read_text() == want_head
 
 
+def test_cli_many_records_batched_path(orc, tmp_path):
+    """A GRU model without attention takes the batched path (dgrp_predict_batch) for short records: 60 records incl.
+    empty-after-stripping, one-base, window-sized, lower-case, CRLF-free plain records and one record that needs the
+    reference parser in between; TSV identical to the oracle pipeline record by record."""
+    from deepgrp_amd.__main__ import main
+    rng = np.random.default_rng(31)
+    recs = {}
+    for k in range(60):
+        n = int(rng.choice([1, 2, 19, 20, 21, 64, 65, 300, 1000, 5000]))
+        recs[f"c{k}"] = "".join(rng.choice(list("ACGTacgt"), size=n))
+    recs["c7"] = "NNNN" + recs["c7"] + "NN"
+    items = list(recs.items())
+    text = "".join(f">{h}\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n" for h, s in items[:30])
+    text += ">odd one\nAC GT\nACGTACGTACGTACGTACGTACGTACGT\n"                   # inner blank: reference loop, splits the batch
+    text += "".join(f">{h}\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n" for h, s in items[30:])
+    fasta = tmp_path / "many.fa"
+    fasta.write_text(text)
+    model_file = os.path.join(GOLDEN, "model_u8_T20.h5")
+    out = tmp_path / "out.tsv"
+    main(["-b", "7", "-s", "4", "-x", "5", "-l", "3", "predict", model_file, str(fasta), "--output", str(out)])
+    want = _expected_tsv(orc, str(fasta), model_file, None, 4, 7, 3, 5, True)
+    assert out.read_text() == want
+    assert want.count("\n") > 100
+
+
 def test_cli_with_lstm_model(orc, tmp_path):
     """`deepgrp predict` with an rnn="LSTM" model file: rows equal the oracle's post-processing of the
     GPU probabilities, probabilities within 1e-3 of the float64 LSTM statement."""
