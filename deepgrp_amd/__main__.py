@@ -175,6 +175,15 @@ class CommandLineParser:
             body = np.char.add(np.char.add(np.char.add(np.char.add(cols[0], "\t"), cols[1]), "\t"), cols[2])
             return prefix + ("\n" + prefix).join(body.tolist()) + "\n"
 
+        def rows_text_batch(filename: str, headers, rows) -> str:
+            """The rows of a batch of records (rows["contig"] = index into `headers`), record order = row order."""
+            if len(rows) == 0:
+                return ""
+            prefixes = np.array(["{}\t{}\t".format(filename, h) for h in headers])[rows["contig"]]
+            cols = [rows[name].astype(np.int64).astype("U") for name in ("start", "end", "label")]
+            body = np.char.add(np.char.add(np.char.add(np.char.add(np.char.add(prefixes, cols[0]), "\t"), cols[1]), "\t"), cols[2])
+            return "\n".join(body.tolist()) + "\n"
+
         def run_record(rec, contig=0):
             if isinstance(rec, DeviceRecord):                 # parsed and encoded on the GPU
                 if rec.length < 0:
@@ -193,7 +202,7 @@ class CommandLineParser:
             else:
                 yield from read_multi_fasta_device(filename)
 
-        def in_order(records, fn, workers: int = int(os.environ.get("DGRP_CLI_WORKERS", "16")), max_bases: int = 1 << 31):
+        def in_order(records, fn, workers: int = int(os.environ.get("DGRP_CLI_WORKERS", "16")), max_bases: int = 1 << 29):
             """`fn(record)` for every (header, record) of the iterable on a small pool of threads, each with its own
             HIP stream; yields (header, result) in input order.  Records are independent (__main__.py:280-292), so
             while one is in its post-processing (whose fixed-point loop waits on the stream) the next ones are
@@ -266,8 +275,7 @@ class CommandLineParser:
                 base = item[0][1].base
                 rows = pipe.run_batch(base, [r.offset for _h, r in item], [r.length for _h, r in item],
                                       [r.startpos for _h, r in item], list(range(len(item))))
-                cuts = np.searchsorted(rows["contig"], np.arange(len(item) + 1))
-                return [h for h, _r in item], [rows[cuts[i]:cuts[i + 1]] for i in range(len(item))]
+                return [h for h, _r in item], rows
             return run_record(item)
 
         try:
@@ -276,9 +284,8 @@ class CommandLineParser:
                     _LOG.info("Processing %s", filename)
                     for key, result in in_order(work_items(records_of(filename)), run_item):
                         if key == "batch":
-                            headers, parts = result
-                            for header, rows in zip(headers, parts):
-                                outstream.write(rows_text(filename, header, rows))
+                            headers, rows = result
+                            outstream.write(rows_text_batch(filename, headers, rows))
                         else:
                             outstream.write(rows_text(filename, key, result))
             else:

@@ -451,6 +451,72 @@ static mss_layout mss_carve(void *work, int64_t n)
     return l;
 }
 
+// One workgroup per record body: count, running offset and scatter tile after tile (a short record is a few tiles;
+// no separate scan, no launch per record).  g = [bad flag, first non-N compact index, last non-N compact index + 1,
+// kept characters] per record (32 words apart).
+__global__ void __launch_bounds__(256) fasta_record_kernel(const uint8_t *__restrict__ raw_base, const int64_t *__restrict__ off,
+                                                           const int64_t *__restrict__ len, const uint8_t *__restrict__ small,
+                                                           uint8_t *__restrict__ idx_base, unsigned long long *__restrict__ gbase)
+{
+    __shared__ uint64_t lds[4];
+    const int64_t r = blockIdx.x;
+    if (!small[r]) return;
+    const int64_t n = len[r];
+    const uint8_t *raw = raw_base + off[r];
+    uint8_t *idx = idx_base + off[r];
+    unsigned long long *g = gbase + r * 32;
+    uint64_t running = 0;
+    bool bad = false;
+    long long first = 0x7fffffffffffffffll, last = -1;
+    for (int64_t t0 = 0; t0 < n; t0 += SCAN_TILE) {
+        const int64_t base = t0 + (int64_t)threadIdx.x * 8;
+        uint32_t b[8];
+        uint64_t c = 0;
+        for (int j = 0; j < 8; ++j) {
+            const int64_t i = base + j;
+            b[j] = i < n ? raw[i] : (uint32_t)'\n';
+            if (i < n) {
+                const bool lineend = b[j] == '\n' || b[j] == '\r';
+                c += lineend ? 0 : 1;
+                if (b[j] >= 128 || (b[j] <= 32 && !lineend)) bad = true;
+                if (b[j] == '\r' && (i + 1 >= n || raw[i + 1] != '\n')) bad = true;
+                if (b[j] == '\n') {
+                    if (i == 0) bad = true;
+                    if (i + 1 < n && raw[i + 1] == '\n') bad = true;
+                    if (i + 2 < n && raw[i + 1] == '\r' && raw[i + 2] == '\n') bad = true;
+                }
+                if (b[j] == '\r' && i == 0) bad = true;
+            }
+        }
+        uint64_t tot = 0;
+        uint64_t ex = block_exclusive_scan(c, &tot, lds) + running;
+        running += tot;
+        for (int j = 0; j < 8; ++j) {
+            if (b[j] == '\n' || b[j] == '\r') continue;
+            idx[ex] = (uint8_t)fasta_class_of(b[j]);
+            if ((b[j] | 0x20u) != 'n') {
+                if ((long long)ex < first) first = (long long)ex;
+                last = (long long)ex + 1;
+            }
+            ++ex;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long f2 = __shfl_xor(first, o), l2 = __shfl_xor(last, o);
+        first = f2 < first ? f2 : first;
+        last = l2 > last ? l2 : last;
+    }
+    const bool anybad = __any(bad);
+    if ((threadIdx.x & 63) == 0) {
+        if (anybad) atomicOr(&g[0], 1ull);
+        if (last >= 0) {
+            atomicMin(&g[1], (unsigned long long)first);
+            atomicMax(&g[2], (unsigned long long)last);
+        }
+    }
+    if (threadIdx.x == 0) g[3] = running;
+}
+
 // Many record bodies of ONE uploaded buffer in a single call: the same three kernels per record, queued back to
 // back, one read-back and one synchronisation for all of them (a file of thousands of short records would
 // otherwise pay an upload and a wait per record).  Record r is the byte range [h_off[r], h_off[r] + h_len[r]) of
@@ -460,7 +526,7 @@ DGRP_EXPORT int64_t dgrp_fasta_batch_workspace_bytes(int64_t nrec, int64_t total
 {
     if (nrec < 0 || total_bytes < 0) return 0;
     // per record: the tiles of its own scan (rounded up) + 3 words, and 256 B of counters
-    return dgrp_align_up(((total_bytes + SCAN_TILE - 1) / SCAN_TILE + 4 * nrec + 8) * 8, 256) + nrec * 256 + 256;
+    return dgrp_align_up(((total_bytes + SCAN_TILE - 1) / SCAN_TILE + 4 * nrec + 8) * 8, 256) + nrec * 256 + dgrp_align_up(nrec * 17, 256) + 256;
 }
 
 DGRP_EXPORT int dgrp_fasta_encode_batch(const uint8_t *d_raw, int64_t nrec, const int64_t *h_off, const int64_t *h_len,
@@ -485,11 +551,25 @@ DGRP_EXPORT int dgrp_fasta_encode_batch(const uint8_t *d_raw, int64_t nrec, cons
     std::vector<unsigned long long> init((size_t)nrec * 32, 0ull);
     for (int64_t r = 0; r < nrec; ++r) init[(size_t)r * 32 + 1] = 0x7fffffffffffffffull;
     DGRP_HIP(hipMemcpyAsync(gbase, init.data(), init.size() * 8, hipMemcpyHostToDevice, stream));
+    // records up to 1 MiB: one workgroup each in ONE launch; larger ones: the three kernels per record
+    const int64_t SMALL_BYTES = 1 << 20;
+    unsigned char *tab = (unsigned char *)(gbase + nrec * 32);           // off[nrec], len[nrec] (int64), small[nrec] (bytes)
+    int64_t *d_off = (int64_t *)tab, *d_len = d_off + nrec;
+    uint8_t *d_small = (uint8_t *)(d_len + nrec);
+    std::vector<uint8_t> small((size_t)nrec);
+    bool any_small = false;
+    for (int64_t r = 0; r < nrec; ++r) { small[(size_t)r] = h_len[r] > 0 && h_len[r] <= SMALL_BYTES; any_small |= small[(size_t)r] != 0; }
+    if (any_small) {
+        DGRP_HIP(hipMemcpyAsync(d_off, h_off, (size_t)nrec * 8, hipMemcpyHostToDevice, stream));
+        DGRP_HIP(hipMemcpyAsync(d_len, h_len, (size_t)nrec * 8, hipMemcpyHostToDevice, stream));
+        DGRP_HIP(hipMemcpyAsync(d_small, small.data(), (size_t)nrec, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(fasta_record_kernel, dim3((unsigned)nrec), dim3(256), 0, stream, d_raw, d_off, d_len, d_small, d_idx, gbase);
+    }
     std::vector<int64_t> grand_at((size_t)nrec, -1);
     int64_t word = 0;
     for (int64_t r = 0; r < nrec; ++r) {
         const int64_t nbytes = h_len[r];
-        if (nbytes == 0) continue;
+        if (nbytes == 0 || small[(size_t)r]) continue;
         const int64_t ntiles = (nbytes + SCAN_TILE - 1) / SCAN_TILE;
         uint64_t *tiles = tiles_base + word;
         uint64_t *grand = tiles + ntiles + 1;
@@ -512,7 +592,7 @@ DGRP_EXPORT int dgrp_fasta_encode_batch(const uint8_t *d_raw, int64_t nrec, cons
         int64_t *info = h_info + 4 * r;
         if (h_len[r] == 0) { info[0] = 1; info[1] = 0; info[2] = 0; info[3] = 0; continue; }
         const unsigned long long *g = hg.data() + (size_t)r * 32;
-        const int64_t tot = (int64_t)htiles[(size_t)grand_at[(size_t)r]];
+        const int64_t tot = small[(size_t)r] ? (int64_t)g[3] : (int64_t)htiles[(size_t)grand_at[(size_t)r]];
         info[0] = g[0] ? 0 : 1;
         info[1] = tot;
         if (g[2] == 0) { info[2] = tot; info[3] = -tot; }

@@ -106,14 +106,22 @@ def read_multi_fasta_file(path: Union[str, os.PathLike]) -> Iterator[Tuple[str, 
 
 class DeviceRecord:
     """A record whose sequence never existed as a Python string: class indices in HBM.
-    `d_idx` is the kept part (leading/trailing N dropped), `startpos` the number of leading N."""
+    `d_idx` is the kept part (leading/trailing N dropped), `startpos` the number of leading N.
+    `base` is the ingest group's buffer and `offset` the position of the kept part in it (records of one group can go
+    to the GPU as a batch); the `d_idx` view is only made when somebody asks for it."""
 
-    __slots__ = ("startpos", "d_idx", "length", "base", "offset")
+    __slots__ = ("startpos", "length", "base", "offset", "_view")
 
     def __init__(self, startpos, d_idx, length, base=None, offset=0):
-        self.startpos, self.d_idx, self.length = startpos, d_idx, length
-        # the ingest group's buffer and the position of d_idx in it: records of one group can go to the GPU as a batch
+        self.startpos, self.length = startpos, length
         self.base, self.offset = base, offset
+        self._view = d_idx
+
+    @property
+    def d_idx(self):
+        if self._view is None:
+            self._view = self.base[self.offset:self.offset + max(self.length, 0)]
+        return self._view
 
 
 def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 256 << 20, group_records: int = 4096):
@@ -138,16 +146,26 @@ def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 25
         return
     # ACCESS_COPY: a private, writable mapping (never written) so that torch accepts views of it
     with open(path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_COPY) as mm:
-        starts = [0]
-        pos = mm.find(b"\n>")
-        while pos != -1:
-            starts.append(pos + 1)
-            pos = mm.find(b"\n>", pos + 1)
-        starts.append(size)
         whole = np.frombuffer(mm, dtype=np.uint8)
         carry_header = ""
         carry_seq: List[str] = []
         try:
+            # chunk table in numpy (a file of 100 000 records would otherwise spend its time in per-record find()s):
+            # chunk starts = file start and every '>' that follows a line feed; end of each chunk's first line
+            blk = 1 << 28                                                      # bounded temporaries on multi-GB files
+            lf_pos = np.concatenate([np.flatnonzero(whole[o:o + blk] == 10) + o for o in range(0, size, blk)] or [np.zeros(0, np.int64)])
+            nxt = lf_pos + 1
+            nxt = nxt[nxt < size]
+            starts_np = np.concatenate([[0], nxt[whole[nxt] == 62], [size]]).astype(np.int64)
+            del nxt
+            k = np.searchsorted(lf_pos, starts_np[:-1])                       # first line feed at or after the chunk start
+            first_lf = np.where(k < lf_pos.size, lf_pos[np.minimum(k, max(lf_pos.size - 1, 0))] if lf_pos.size else size, size)
+            head_end_np = np.minimum(first_lf, starts_np[1:])                 # no line feed inside the chunk: header runs to its end
+            body0_np = np.where(first_lf < starts_np[1:], first_lf + 1, starts_np[1:])
+            gt_np = whole[starts_np[:-1]] == 62
+            del lf_pos, k, first_lf
+            starts = starts_np.tolist()
+            head_ends, body0_all, gt_all = head_end_np.tolist(), body0_np.tolist(), gt_np.tolist()
             nchunks = len(starts) - 1
             c0 = 0
             while c0 < nchunks:
@@ -155,14 +173,8 @@ def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 25
                 c1 = c0 + 1
                 while c1 < nchunks and c1 - c0 < group_records and starts[c1 + 1] - starts[c0] <= group_bytes:
                     c1 += 1
-                heads, body0s, cand = [], [], []
-                for c in range(c0, c1):
-                    a, b = starts[c], starts[c + 1]
-                    nl = mm.find(b"\n", a, b)
-                    head = mm[a:(b if nl == -1 else nl)]
-                    heads.append(head)
-                    body0s.append(b if nl == -1 else nl + 1)
-                    cand.append(mm[a:a + 1] == b">" and head.isascii())
+                body0s = body0_all[c0:c1]
+                cand = [gt_all[c] and mm[starts[c]:head_ends[c]].isascii() for c in range(c0, c1)]
                 g0, g1 = starts[c0], starts[c1]
                 infos = np.zeros((c1 - c0, 4), np.int64)
                 d_idx = None
@@ -176,17 +188,18 @@ def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 25
                     check(L.dgrp_fasta_encode_batch(d_raw.data_ptr(), c1 - c0, off.ctypes.data, ln.ctypes.data, d_idx.data_ptr(),
                                                     infos.ctypes.data, work.data_ptr(), wb, stream_ptr()), "dgrp_fasta_encode_batch")
                     del d_raw, work
+                info_rows = infos.tolist()                   # plain ints: numpy scalar indexing per record is slow
                 for i, c in enumerate(range(c0, c1)):
                     a, b = starts[c], starts[c + 1]
-                    if cand[i] and infos[i, 0] == 1:
+                    if cand[i] and info_rows[i][0] == 1:
                         if carry_header:
                             yield carry_header, "".join(carry_seq)
                         carry_header, carry_seq = "", []
-                        header = heads[i].decode("ascii").strip()[1:]
+                        header = mm[a:head_ends[c]].decode("ascii").strip()[1:]
                         if header:
-                            st, kept = int(infos[i, 2]), int(infos[i, 3])
+                            st, kept = info_rows[i][2], info_rows[i][3]
                             lo = body0s[i] - g0 + st
-                            yield header, DeviceRecord(st, d_idx[lo:lo + max(kept, 0)], kept, d_idx, lo)
+                            yield header, DeviceRecord(st, None, kept, d_idx, lo)
                         continue
                     text = io.TextIOWrapper(io.BytesIO(mm[a:b]), encoding=None, newline=None)
                     for line in text:
