@@ -245,7 +245,15 @@ class CommandLineParser:
                     h0, f0, w0 = pending.popleft()
                     yield h0, f0.result()
 
-        SMALL, BATCH_RECORDS, BATCH_BASES = 1 << 18, 4096, 64 << 20
+        SMALL, BATCH_RECORDS, BATCH_BYTES = 1 << 18, 4096, 4 << 30
+        T_, UP_ = model.vecsize, (model.units + 31) // 32 * 32
+
+        def batch_cost(n: int) -> int:
+            """Workspace bytes a record of n bases adds to a batch (attention: the avg[t] spill of its windows dominates)."""
+            cost = 80 * n
+            if model.attention:
+                cost += len(range(0, n - T_, args.step_size)) * T_ * (UP_ * 2 + model.classes * 4)
+            return cost
 
         def work_items(records):
             """Consecutive short records of one ingest buffer become one item (a list), everything else stays single:
@@ -260,11 +268,11 @@ class CommandLineParser:
 
             for header, rec in records:
                 small = (pipe.batchable() and isinstance(rec, DeviceRecord) and rec.base is not None and 1 <= rec.length <= SMALL)
-                if small and group and (group[0][1].base is not rec.base or len(group) >= BATCH_RECORDS or bases + rec.length > BATCH_BASES):
+                if small and group and (group[0][1].base is not rec.base or len(group) >= BATCH_RECORDS or bases + batch_cost(rec.length) > BATCH_BYTES):
                     yield from flush()
                 if small:
                     group.append((header, rec))
-                    bases += rec.length
+                    bases += batch_cost(rec.length)
                 else:
                     yield from flush()
                     yield header, rec

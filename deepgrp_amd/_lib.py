@@ -52,7 +52,7 @@ _SIGNATURES = {
     "dgrp_segments": (cint, [vp, i64, i64, i32, vp, i64, vp, vp, i64, vp]),
     "dgrp_record_workspace_bytes": (i64, [vp, i64, i64, cint]),
     "dgrp_predict_record": (cint, [vp, vp, i64, i64, i64, cint, cint, cint, i64, i32, vp, i64, C.POINTER(i64), vp, i64, vp]),
-    "dgrp_batch_workspace_bytes": (i64, [vp, i64, vp]),
+    "dgrp_batch_workspace_bytes": (i64, [vp, i64, vp, i64]),
     "dgrp_predict_batch": (cint, [vp, vp, i64, vp, vp, vp, vp, i64, i64, cint, cint, vp, i64, C.POINTER(i64), vp, i64, vp]),
     "dgrp_confusion_matrix": (cint, [vp, vp, i64, cint, vp, vp, vp]),
     "dgrp_filter_segments": (cint, [vp, vp, i64, i64, vp]),

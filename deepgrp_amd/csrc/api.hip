@@ -443,10 +443,10 @@ int dgrp_batch_segments(const int8_t *d_labels, const uint8_t *d_marks, int64_t 
                         int64_t *d_count, void *d_work, int64_t work_bytes, hipStream_t stream);
 
 struct batch_layout {
-    int64_t out, scores, cls, labels, marks, count, recs, wgf, start, len, spos, contig, post, post_bytes, bytes;
+    int64_t out, scores, cls, labels, marks, count, recs, wgf, start, len, spos, contig, post, post_bytes, avg, pl, bytes;
 };
 
-static batch_layout batch_carve(const dgrp_model *m, int64_t nrec, int64_t total_rows)
+static batch_layout batch_carve(const dgrp_model *m, int64_t nrec, int64_t total_rows, int64_t total_windows)
 {
     batch_layout l;
     int64_t p = 0;
@@ -465,8 +465,18 @@ static batch_layout batch_carve(const dgrp_model *m, int64_t nrec, int64_t total
     l.contig = take(nrec * 4);
     l.post_bytes = std::max<int64_t>(std::max<int64_t>(dgrp_mss_batch_workspace_bytes(total_rows, nrec), dgrp_segments_workspace_bytes(total_rows)), 4096);
     l.post = take(l.post_bytes);
+    // attention: avg[t] of every window (fp16) and the avg half of the logits
+    l.avg = take(m->attention ? total_windows * m->T * (int64_t)m->UP * 2 : 0);
+    l.pl = take(m->attention ? total_windows * m->T * (int64_t)m->C * 4 : 0);
     l.bytes = p;
     return l;
+}
+
+static int64_t batch_windows(const dgrp_model *m, int64_t nrec, const int64_t *h_n, int64_t s)
+{
+    int64_t w = 0;
+    for (int64_t r = 0; r < nrec; ++r) w += dgrp_window_count(h_n[r], m->T, s);
+    return w;
 }
 
 static int64_t batch_rows(int64_t nrec, const int64_t *h_n)
@@ -476,12 +486,12 @@ static int64_t batch_rows(int64_t nrec, const int64_t *h_n)
     return rows;
 }
 
-DGRP_EXPORT int64_t dgrp_batch_workspace_bytes(const dgrp_model *m, int64_t nrec, const int64_t *h_n)
+DGRP_EXPORT int64_t dgrp_batch_workspace_bytes(const dgrp_model *m, int64_t nrec, const int64_t *h_n, int64_t s)
 {
-    if (!m || nrec < 0 || (nrec > 0 && !h_n)) return 0;
+    if (!m || nrec < 0 || s < 1 || (nrec > 0 && !h_n)) return 0;
     for (int64_t r = 0; r < nrec; ++r)
         if (h_n[r] < 1) return 0;
-    return batch_carve(m, nrec, batch_rows(nrec, h_n)).bytes;
+    return batch_carve(m, nrec, batch_rows(nrec, h_n), batch_windows(m, nrec, h_n, s)).bytes;
 }
 
 DGRP_EXPORT int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t nrec, const int64_t *h_idx_off,
@@ -493,13 +503,15 @@ DGRP_EXPORT int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, in
     DGRP_REQUIRE(m && nrec >= 0 && s >= 1 && batch >= 1 && cap >= 0 && h_count, "dgrp_predict_batch: bad arguments");
     *h_count = 0;
     if (nrec == 0) return DGRP_OK;
-    DGRP_REQUIRE(m->cell == 0 && !m->attention, "dgrp_predict_batch: GRU models without attention only (use dgrp_predict_record)");
+    DGRP_REQUIRE(m->cell == 0, "dgrp_predict_batch: GRU models only (use dgrp_predict_record)");
     DGRP_REQUIRE(d_idx && h_idx_off && h_n && h_startpos && h_contig && d_work && (cap == 0 || d_records), "dgrp_predict_batch: NULL pointer");
     for (int64_t r = 0; r < nrec; ++r)
         DGRP_REQUIRE(h_n[r] >= 1 && h_idx_off[r] >= 0, "dgrp_predict_batch: record %lld: empty records do not belong in a batch", (long long)r);
     const int64_t rows = batch_rows(nrec, h_n);
     DGRP_REQUIRE(rows < (1ll << 31), "dgrp_predict_batch: %lld rows in one batch (limit 2^31)", (long long)rows);
-    const batch_layout l = batch_carve(m, nrec, rows);
+    const int64_t windows = batch_windows(m, nrec, h_n, s);
+    DGRP_REQUIRE(windows < (1ll << 31), "dgrp_predict_batch: too many windows in one batch");
+    const batch_layout l = batch_carve(m, nrec, rows, windows);
     if (work_bytes < l.bytes) {
         dgrp_set_error("dgrp_predict_batch: workspace %lld < %lld bytes", (long long)work_bytes, (long long)l.bytes);
         return DGRP_ENOMEM;
@@ -507,11 +519,13 @@ DGRP_EXPORT int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, in
     char *w = (char *)d_work;
     // ---- tables
     std::vector<int64_t> recs((size_t)nrec * 8, 0), wgf((size_t)nrec + 1, 0), start((size_t)nrec + 1, 0);
+    int64_t wfirst = 0;
     for (int64_t r = 0; r < nrec; ++r) {
         const int64_t nwin = dgrp_window_count(h_n[r], m->T, s);
         const dgrp_placement pl = dgrp_make_placement(nwin, batch);
         int64_t *e = recs.data() + (size_t)r * 8;
-        e[0] = h_idx_off[r]; e[1] = h_n[r]; e[2] = start[(size_t)r]; e[3] = nwin; e[4] = pl.nfullB; e[5] = pl.shift;
+        e[0] = h_idx_off[r]; e[1] = h_n[r]; e[2] = start[(size_t)r]; e[3] = nwin; e[4] = pl.nfullB; e[5] = pl.shift; e[6] = wfirst;
+        wfirst += nwin;
         wgf[(size_t)r + 1] = wgf[(size_t)r] + (nwin + 15) / 16;
         start[(size_t)r + 1] = start[(size_t)r] + dgrp_align_up(h_n[r], 64);
     }
@@ -524,8 +538,20 @@ DGRP_EXPORT int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, in
     // ---- A3-A6 for all records: one launch
     float *out = (float *)(w + l.out);
     DGRP_HIP(hipMemsetAsync(out, 0, (size_t)rows * m->C * 4, stream));
-    int rc = dgrp_gru_launch_batch(m, d_idx, s, w + l.recs, (const int64_t *)(w + l.wgf), nrec, wgf[(size_t)nrec], out, stream);
-    if (rc) return rc;
+    int rc;
+    if (!m->attention) {
+        rc = dgrp_gru_launch_batch(m, d_idx, s, w + l.recs, (const int64_t *)(w + l.wgf), nrec, wgf[(size_t)nrec], 0, out, nullptr, stream);
+        if (rc) return rc;
+    } else {
+        // GRU pre-pass for all windows (avg[t] and the avg half of the logits, windows numbered through the batch),
+        // then the attention kernel with the same record table for placement
+        rc = dgrp_gru_launch_batch(m, d_idx, s, w + l.recs, (const int64_t *)(w + l.wgf), nrec, wgf[(size_t)nrec], 2,
+                                   (float *)(w + l.pl), w + l.avg, stream);
+        if (rc) return rc;
+        rc = dgrp_attention_launch_recs(m, s, dgrp_placement{ 0, 0 }, 0, windows, 1, rows, w + l.avg, (const float *)(w + l.pl), out,
+                                        w + l.recs, nrec, stream);
+        if (rc) return rc;
+    }
     // ---- A7: scores over all rows, then padding rows to (0.0, class 0) and the record marks
     double *scores = (double *)(w + l.scores);
     int8_t *cls = (int8_t *)(w + l.cls), *labels = (int8_t *)(w + l.labels);

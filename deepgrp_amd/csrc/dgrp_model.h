@@ -25,6 +25,9 @@ int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, 
                           hipStream_t stream);
 // batched records (mode 0): see gru_kernel.hip
 int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, const void *d_recs, const int64_t *d_wg_first,
-                          int64_t nrec, int64_t total_groups, float *d_out, hipStream_t stream);
-// layout of one record-table entry (64 bytes): idx_off, n, out_row, nwin, place.nfullB, place.shift, 0, 0
+                          int64_t nrec, int64_t total_groups, int mode, float *d_out, void *d_avg, hipStream_t stream);
+int dgrp_attention_launch_recs(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
+                               int merge, int64_t n, const void *d_avg, const float *d_pl, float *d_out,
+                               const void *d_recs, int64_t nrec, hipStream_t stream);
+// layout of one record-table entry (64 bytes): idx_off, n, out_row, nwin, place.nfullB, place.shift, win_first, 0
 

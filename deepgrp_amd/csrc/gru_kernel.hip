@@ -46,7 +46,8 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 struct gru_rec {
     int64_t idx_off, n, out_row, nwin;
     dgrp_placement place;
-    int64_t pad_[2];
+    int64_t win_first;   // windows of the records before this one (row of its first window in the avg / pl spill)
+    int64_t pad_;
 };
 
 struct gru_params {
@@ -66,6 +67,7 @@ struct gru_params {
     const struct gru_rec *recs;
     const int64_t *wg_first;
     int64_t nrec;
+    int64_t avgw;         // modes 1, 2: row of window w0 in the output / spill buffers (batched records: the record's first)
 };
 
 // The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 {
     gru_params p = pin;
     int64_t bid = blockIdx.x;
-    if (MODE == 0 && pin.recs) {
+    if (MODE != 1 && pin.recs) {
         // which record: last r with wg_first[r] <= blockIdx.x (uniform over the workgroup: scalar loads)
         int64_t lo_r = 0, hi_r = pin.nrec;
         while (hi_r - lo_r > 1) {
@@ -158,10 +160,11 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         bid = (int64_t)blockIdx.x - pin.wg_first[lo_r];
         p.idx = pin.idx + rc.idx_off;
         p.n = rc.n;
-        p.out = pin.out + rc.out_row * pin.C;
+        if (MODE == 0) p.out = pin.out + rc.out_row * pin.C;
         p.place = rc.place;
         p.w0 = 0;
         p.nw = rc.nwin;
+        p.avgw = rc.win_first;
     }
     constexpr bool PIPE = DGRP_PIPE;
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;   // HS: padded row pitch (halves) -> conflict-free b128 reads
@@ -219,7 +222,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         int64_t r0 = -1;
         int off = -1;
         if (tid < nvalid) {
-            r0 = MODE == 0 ? dgrp_place_row(p.place, wg_w + tid, p.s) : (wg_w + tid - p.w0) * (int64_t)T;
+            r0 = MODE == 0 ? dgrp_place_row(p.place, wg_w + tid, p.s) : (wg_w + tid - p.w0 + p.avgw) * (int64_t)T;
             if (MODE == 0 && r0 >= lo && r0 - lo + T <= p.ospan) off = (int)(r0 - lo);
         }
         row0s[tid] = r0;
@@ -338,7 +341,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         if (MODE == 2 && (lane & 15) < nvalid) {
             // attention: keep avg[t] (fp16: it is an fp16 MFMA operand everywhere else too) for the second kernel
             const half8 av = (a0 + a1) * (_Float16)0.5f;
-            *reinterpret_cast<half8 *>(p.avg + ((wg_w + (lane & 15) - p.w0) * (int64_t)T + tt) * UP + 32 * wave + 8 * (lane >> 4)) = av;
+            *reinterpret_cast<half8 *>(p.avg + ((wg_w + (lane & 15) - p.w0 + p.avgw) * (int64_t)T + tt) * UP + 32 * wave + 8 * (lane >> 4)) = av;
         }
         f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
@@ -706,7 +709,28 @@ struct att_params {
     dgrp_placement place;
     int T, C, UP, merge;
     int ospan;           // wave kernel, merge: rows of the workgroup's LDS output image
+    // batched records: window wl belongs to record r with recs[r].win_first <= wl; placement, first output row and
+    // row limit are the record's own
+    const gru_rec *recs;
+    int64_t nrec;
 };
+
+// first merged row of (global) window wl and the row limit of its record
+__device__ __forceinline__ int64_t att_window_row(const att_params &p, int64_t wl, int64_t *limit)
+{
+    if (!p.recs) {
+        *limit = p.n;
+        return dgrp_place_row(p.place, p.w0 + wl, p.s);
+    }
+    int64_t lo = 0, hi = p.nrec;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (p.recs[mid].win_first <= wl) lo = mid; else hi = mid;
+    }
+    const gru_rec rc = p.recs[lo];
+    *limit = rc.out_row + rc.n;
+    return rc.out_row + dgrp_place_row(rc.place, wl - rc.win_first, p.s);
+}
 
 // One workgroup (256 threads) per window, ONE pass over the window's avg[t] tile (read from HBM once):
 // tiles of 64 time steps are staged in LDS; scores e[t] = sum_k scale[k] tanh(q[k] + avg[t,k]) are
@@ -788,8 +812,8 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
         cl[tid] = acc * inv;
     }
     __syncthreads();
-    const int64_t w = p.w0 + wl;
-    const int64_t row0 = p.merge ? dgrp_place_row(p.place, w, p.s) : wl * (int64_t)T;
+    int64_t limit = p.n;
+    const int64_t row0 = p.merge ? att_window_row(p, wl, &limit) : wl * (int64_t)T;
     const float *pl = p.pl + wl * (int64_t)T * C;
     for (int t = tid; t < T; t += 256) {
         float lg[16];
@@ -800,7 +824,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
         for (int c = 0; c < C; ++c) {
             const float v = lg[c] / den;
             if (p.merge) {
-                if (row0 + t < p.n) atomicMax(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
+                if (row0 + t < limit) atomicMax(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
             } else {
                 p.out[(row0 + t) * C + c] = v;
             }
@@ -851,7 +875,8 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
     const int nvalid = (int)min((int64_t)ATT_WPB, p.nw - wg0);
     int64_t lo = 0;
     if (p.merge) {
-        const int64_t a = dgrp_place_row(p.place, p.w0 + wg0, p.s), b = dgrp_place_row(p.place, p.w0 + wg0 + nvalid - 1, p.s);
+        int64_t lim_;
+        const int64_t a = att_window_row(p, wg0, &lim_), b = att_window_row(p, wg0 + nvalid - 1, &lim_);
         lo = a < b ? a : b;
         for (int i = threadIdx.x; i < p.ospan * C; i += 256) obuf[i] = 0u;
         __syncthreads();
@@ -993,7 +1018,8 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
         ctop[c] = part;
     }
     // ---- logits[t] = ctx.W_top + (avg[t].W_bot + b), softmax over classes, merge / store: lane <-> t
-    const int64_t row0 = p.merge ? dgrp_place_row(p.place, p.w0 + wl, p.s) : wl * (int64_t)T;
+    int64_t limit = p.n;
+    const int64_t row0 = p.merge ? att_window_row(p, wl, &limit) : wl * (int64_t)T;
     const int off = p.merge && row0 >= lo && row0 - lo + T <= p.ospan ? (int)(row0 - lo) : -1;
     const float *pl = p.pl + wl * (int64_t)T * C;
     // Straight-line over a compile-time class bound (addresses clamped, surplus classes at -inf): with a runtime
@@ -1019,8 +1045,9 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
             if (c < C) {
                 const float v = lg[c] * rden;
                 if (!p.merge) p.out[(row0 + t) * C + c] = v;
+                else if (row0 + t >= limit) { }                  // beyond the record (partial-batch placement): dropped
                 else if (off >= 0) lds_atomic_max(obuf + (off + t) * C + c, __float_as_uint(v));
-                else if (row0 + t < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
+                else global_atomic_max(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
             }
     }
   }
@@ -1096,7 +1123,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = mode;
     p.Tp = (int)dgrp_align_up(m->T, 16);
     p.stamps = nullptr;
-    p.recs = nullptr; p.wg_first = nullptr; p.nrec = 0;
+    p.recs = nullptr; p.wg_first = nullptr; p.nrec = 0; p.avgw = 0;
 #ifdef DGRP_STAMP
     static uint64_t *d_stamps = nullptr;
     const int64_t ngroups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
@@ -1160,21 +1187,21 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
 // GRU forward + merge for a batch of records in ONE launch (mode 0, no attention): the record table and the
 // cumulative workgroup counts are device arrays prepared by the caller (api.hip: dgrp_predict_batch)
 int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, const void *d_recs, const int64_t *d_wg_first,
-                          int64_t nrec, int64_t total_groups, float *d_out, hipStream_t stream)
+                          int64_t nrec, int64_t total_groups, int mode, float *d_out, void *d_avg, hipStream_t stream)
 {
     if (nrec <= 0 || total_groups <= 0) return DGRP_OK;
-    DGRP_REQUIRE(m->cell == 0 && !m->attention && m->NW <= 8, "dgrp_gru_launch_batch: GRU models without attention only");
+    DGRP_REQUIRE(m->cell == 0 && m->NW <= 8 && (mode == 0 || mode == 2), "dgrp_gru_launch_batch: GRU models only");
     gru_params p;
     p.idx = d_idx; p.n = 0; p.s = s; p.w0 = 0; p.nw = 0; p.place = dgrp_placement{ 0, 0 };
-    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = nullptr;
-    p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = 0;
+    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = (_Float16 *)d_avg;
+    p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = mode;
     p.Tp = (int)dgrp_align_up(m->T, 16);
     p.stamps = nullptr;
-    p.recs = (const gru_rec *)d_recs; p.wg_first = d_wg_first; p.nrec = nrec;
+    p.recs = (const gru_rec *)d_recs; p.wg_first = d_wg_first; p.nrec = nrec; p.avgw = 0;
     const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
     const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
     const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed) / (m->C * 4);
-    p.ospan = (int)(want < cap ? want : cap);
+    p.ospan = mode == 0 ? (int)(want < cap ? want : cap) : 0;
     if (p.ospan < m->T) p.ospan = 0;
     const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
@@ -1190,15 +1217,17 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     }
 }
 
-int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
-                          int merge, int64_t n, const void *d_avg, const float *d_pl, float *d_out,
-                          hipStream_t stream)
+// d_recs / nrec: record table of a batch (windows numbered through the batch, n = rows of the whole batch) or NULL / 0
+int dgrp_attention_launch_recs(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
+                               int merge, int64_t n, const void *d_avg, const float *d_pl, float *d_out,
+                               const void *d_recs, int64_t nrec, hipStream_t stream)
 {
     if (nw <= 0) return DGRP_OK;
     att_params p;
     p.avg = (const _Float16 *)d_avg; p.pl = d_pl; p.scale = m->d_scale; p.wtop = m->d_wtop; p.out = d_out;
     p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
     p.T = m->T; p.C = m->C; p.UP = m->UP; p.merge = merge;
+    p.recs = (const gru_rec *)d_recs; p.nrec = nrec;
     const size_t lds = (size_t)ATT_TT * (m->UP + 8) * 2 + (size_t)(3 * m->UP + 4 * ATT_TT + ATT_TT + 8 + 16) * sizeof(float);
     DGRP_REQUIRE(nw < (1ll << 31), "too many windows in one launch");
     p.ospan = 0;
@@ -1233,3 +1262,11 @@ int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, 
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
 }
+
+int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
+                          int merge, int64_t n, const void *d_avg, const float *d_pl, float *d_out,
+                          hipStream_t stream)
+{
+    return dgrp_attention_launch_recs(m, s, place, w0, nw, merge, n, d_avg, d_pl, d_out, nullptr, 0, stream);
+}
+

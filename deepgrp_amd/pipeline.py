@@ -263,8 +263,8 @@ class ContigPipeline:
         return host.view(SEGMENT_DTYPE).copy()
 
     def batchable(self) -> bool:
-        """dgrp_predict_batch covers GRU models without attention on the MSS path."""
-        return self.use_mss and not self.model.attention and getattr(self.model, "rnn", "GRU") == "GRU" and self.event_log is None
+        """dgrp_predict_batch covers GRU models (with or without attention) on the MSS path."""
+        return self.use_mss and getattr(self.model, "rnn", "GRU") == "GRU" and self.event_log is None
 
     def run_batch(self, d_base: torch.Tensor, offsets, lengths, startposes, contigs) -> np.ndarray:
         """Segment records of MANY short records whose class indices lie in one device buffer (record r: `lengths[r]`
@@ -278,7 +278,7 @@ class ContigPipeline:
         sp = np.ascontiguousarray(startposes, np.int64)
         cg = np.ascontiguousarray(contigs, np.int32)
         dev = d_base.device
-        wb = L.dgrp_batch_workspace_bytes(self.model.handle, nrec, ln.ctypes.data)
+        wb = L.dgrp_batch_workspace_bytes(self.model.handle, nrec, ln.ctypes.data, self.step)
         if wb <= 0:
             raise ValueError("run_batch: every record of a batch needs at least one base")
         work = torch.empty(wb, dtype=torch.uint8, device=dev)

@@ -60,15 +60,16 @@ def test_mss_labels_batch_vs_oracle(dev, orc, style, ml, xd):
         np.testing.assert_array_equal(got[a:a + n], want[a:a + n], err_msg=f"record {i} n={n}")
 
 
-@pytest.mark.parametrize("u,T,s,B", [(128, 200, 50, 256), (64, 40, 7, 9), (32, 30, 4, 7), (160, 50, 10, 16)])
-def test_predict_batch_equals_record_by_record(dev, orc, u, T, s, B):
+@pytest.mark.parametrize("u,T,s,B,att", [(128, 200, 50, 256, False), (64, 40, 7, 9, False), (32, 30, 4, 7, False), (160, 50, 10, 16, False),
+                                         (60, 342, 50, 256, True), (64, 40, 7, 9, True), (128, 30, 4, 7, True), (16, 70, 3, 5, True)])
+def test_predict_batch_equals_record_by_record(dev, orc, u, T, s, B, att):
     """dgrp_predict_batch (one GRU launch, batched post-processing) against dgrp_predict_record per record: identical
     segment rows -- incl. records shorter than a window, of exactly one window, 64-aligned lengths and the
     partial-batch placement."""
     import torch
     from deepgrp_amd.pipeline import ContigPipeline, DeviceModel
-    w = orc.Weights.random(u, 5, T, False, seed=u, gain=3.0)
-    m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T)
+    w = orc.Weights.random(u, 5, T, att, seed=u, gain=3.0)
+    m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
     rng = np.random.default_rng(u + T)
     lens = [1, 2, T - 1, T, T + 1, 64, 128, T + s, T + 16 * s, 3 * T + 7, 4097] + [int(x) for x in rng.integers(1, 6000, 30)]
     gaps = rng.integers(0, 37, len(lens))                     # records sit at arbitrary byte offsets of the buffer
