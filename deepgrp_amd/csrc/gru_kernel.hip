@@ -1145,6 +1145,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
         if (p.ospan < m->T) p.ospan = 0;
     }
     const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
+    DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T, fixed);
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
     if (m->cell == 1) {
@@ -1204,6 +1205,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     p.ospan = mode == 0 ? (int)(want < cap ? want : cap) : 0;
     if (p.ospan < m->T) p.ospan = 0;
     const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
+    DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T, fixed);
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
     switch (m->NW) {
     case 1: return launch_gru<1>(p, total_groups, lds, m->onercp != 0, stream);

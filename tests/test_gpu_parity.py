@@ -446,3 +446,22 @@ def test_pipeline_end_to_end(dev, orc, u, T, attention, use_mss):
     np.testing.assert_array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3), want)
     assert st == 7
     dm.close()
+
+
+def test_window_size_beyond_lds_is_refused(dev, orc):
+    """The fused kernel stages a workgroup's 16 windows in LDS: a window size whose staging exceeds 160 KiB is an error
+    with a message, not a failed launch."""
+    from deepgrp_amd._lib import DgrpError
+    rng = np.random.default_rng(0)
+    w, dm = _model(orc, 32, 12000, False, 1.0)
+    idx = _seq_idx(rng, 12000 + 64)
+    with pytest.raises(DgrpError, match="do not fit"):
+        dm.forward_windows(_t(idx, dev), 16, 0, 2)
+    dm.close()
+    # a long but feasible window still runs
+    w, dm = _model(orc, 32, 4000, False, 1.0)
+    idx = _seq_idx(rng, 4000 + 64)
+    got = dm.forward_windows(_t(idx, dev), 16, 0, 2).cpu().numpy()
+    want = orc.nn_forward(idx, w, 16, 0, 2, np.float64)
+    assert np.abs(got - want).max() < 1e-3
+    dm.close()
