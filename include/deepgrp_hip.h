@@ -119,7 +119,9 @@ int dgrp_model_flags(const dgrp_model *m);
 /* ---- A4: model.predict_on_batch (deepgrp/prediction.py:106)
  * Bytes of scratch HBM dgrp_forward_* needs for `nw` windows in one call. */
 int64_t dgrp_forward_workspace_bytes(const dgrp_model *m, int64_t nw);
-/* Class probabilities [nw, T, C] float32 of windows w0 .. w0+nw-1 of the index array. */
+/* Class probabilities [nw, T, C] float32 of windows w0 .. w0+nw-1 of the index array.  (A workgroup stages its 16
+ * windows in LDS: 16 T bytes next to ~25 KiB of state at 128 units, so T up to about 8 000; larger windows are
+ * refused with DGRP_EINVAL.) */
 int dgrp_forward_windows(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s,
                          int64_t w0, int64_t nw, float *d_probs, void *d_work, int64_t work_bytes,
                          void *stream);
