@@ -17,7 +17,6 @@ from typing import Optional, Tuple
 import numpy as np
 import torch
 
-from . import _lib
 from ._lib import check, lib
 
 SEGMENT_DTYPE = np.dtype([("start", "<i8"), ("end", "<i8"), ("label", "<i4"), ("contig", "<i4")])

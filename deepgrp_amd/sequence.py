@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ._lib import check, lib
-from .pipeline import SEGMENT_DTYPE, ContigPipeline, require_gpu, stream_ptr
+from .pipeline import ContigPipeline, require_gpu, stream_ptr
 
 
 def one_hot_encode_dna_sequence(sequence: str) -> Tuple[int, np.ndarray]:
