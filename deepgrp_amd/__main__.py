@@ -319,7 +319,16 @@ class CommandLineParser:
                     allrows = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
                 else:
                     mine = shard_contigs([length(r[2]) for r in records], world)[rank]
-                    parts = [run_record(records[i][2], contig=i) for i in mine]
+                    # this rank's share through the same pool / batching as the single-process path, keyed by record index
+                    parts = []
+                    for key, result in in_order(work_items((i, records[i][2]) for i in mine), run_item):
+                        if key == "batch":
+                            ids, rows = result
+                            rows["contig"] = np.asarray(ids, np.int32)[rows["contig"]]
+                        else:
+                            rows = result
+                            rows["contig"] = key
+                        parts.append(rows)
                     local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
                     allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
                 if rank == 0:

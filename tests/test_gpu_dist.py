@@ -81,3 +81,46 @@ def test_split_contigs_two_ranks_on_one_gpu(tmp_path):
         assert p.exitcode == 0
     assert open(split).read() == open(single).read()
     assert open(single).read().count("\n") > 10
+
+
+def _shard_worker(rank, world, port, fasta, model, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      DGRP_DIST_BACKEND="gloo")
+    from deepgrp_amd.__main__ import main
+    main(["-b", "7", "predict", model, fasta, "--output", out])
+
+
+def test_contig_sharding_two_ranks_many_records(tmp_path):
+    """Contig sharding with 2 ranks (both on GPU 0, gloo transport) over a file of 300 short and 2 longer records: every
+    rank batches its share (dgrp_predict_batch), rank 0 gathers; TSV byte-identical to the single-process run."""
+    import torch.multiprocessing as mp
+    from deepgrp_amd import model as dgmodel, synthetic
+    from deepgrp_amd.__main__ import main
+    w = synthetic.trained_weights()
+    mpath = str(tmp_path / "m.hdf5")
+    dgmodel.save_keras_hdf5(mpath, w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, vecsize=200)
+    raw = synthetic.synthetic_chromosome(1_200_000, contig=3, flank=1000)[5000:-5000]
+    import numpy as np
+    rng = np.random.default_rng(1)
+    fa = tmp_path / "many.fa"
+    pos = 0
+    with open(fa, "wb") as fh:
+        for k in range(302):
+            n = 300_000 if k in (17, 200) else int(rng.integers(1, 3000))
+            seq = raw[pos:pos + n]
+            pos += n
+            fh.write(b">r%d\n" % k + b"\n".join(seq[i:i + 70] for i in range(0, len(seq), 70)) + b"\n")
+    single = str(tmp_path / "single.tsv")
+    main(["-b", "7", "predict", mpath, str(fa), "--output", single])
+    sharded = str(tmp_path / "sharded.tsv")
+    ctx = mp.get_context("spawn")
+    port = 29600 + os.getpid() % 150
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, str(fa), mpath, sharded)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    assert open(sharded).read() == open(single).read()
+    assert open(single).read().count("\n") > 300
+
