@@ -1,0 +1,63 @@
+"""Randomised parity sweep (not part of the test suite): random model shapes / window / step / batch / record
+lengths; (1) probabilities against the float64 oracle, (2) the one-call record path against the oracle's
+post-processing of the GPU's probabilities, (3) the batched path against the record path.  tools/fuzz_parity.py [seconds]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc
+from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, require_gpu
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120
+dev = require_gpu()
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end = time.time() + budget
+it = 0
+worst = 0.0
+while time.time() < t_end:
+    it += 1
+    u = int(rng.choice([4, 8, 16, 31, 32, 33, 60, 64, 65, 96, 100, 128, 129, 160, 200, 256]))
+    T = int(rng.choice([1, 2, 5, 16, 17, 30, 63, 64, 65, 100, 200, 342]))
+    s = int(rng.integers(1, 2 * T + 2))
+    B = int(rng.choice([1, 2, 7, 16, 256]))
+    att = bool(rng.integers(0, 2))
+    gain = float(rng.choice([0.5, 1.0, 2.0, 3.0]))
+    ml, xd = [(50, 50), (3, 10), (10, 0), (0, -1), (1, 1)][int(rng.integers(0, 5))]
+    w = orc.Weights.random(u, 5, T, att, seed=int(rng.integers(0, 1 << 30)), gain=gain)
+    m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    pipe = ContigPipeline(m, s, B, ml, xd)
+    lens = [int(x) for x in rng.choice([1, 2, T, T + 1, T + s, 64, 65, 500, 3000, 9000], size=6)]
+    offs, pos = [], 0
+    for n in lens:
+        pos += int(rng.integers(0, 9)); offs.append(pos); pos += n
+    base = rng.choice(5, size=pos + 3, p=[.24, .25, .25, .24, .02]).astype(np.uint8)
+    d_base = torch.from_numpy(base).to(dev)
+    tag = f"it {it}: u={u} T={T} s={s} B={B} att={att} gain={gain} mss=({ml},{xd}) lens={lens}"
+    try:
+        singles = []
+        for i, (o, n) in enumerate(zip(offs, lens)):
+            idx = base[o:o + n]
+            d_idx = d_base[o:o + n].clone()
+            rows = pipe.run_idx(d_idx, 11, contig=i)
+            singles.append(rows)
+            nwin = orc.window_count(n, T, s)
+            if nwin and n <= 3000:
+                nw = min(nwin, 24)
+                got = m.forward_windows(d_idx, s, 0, nw).cpu().numpy()
+                want = orc.nn_forward(idx, w, s, 0, nw, np.float64)
+                err = float(np.abs(got - want).max())
+                worst = max(worst, err)
+                assert err < 1e-3, f"forward error {err}"
+            probs = m.forward_windows(d_idx, s, 0, nwin).cpu().numpy() if nwin else np.zeros((0, T, 5), np.float32)
+            merged = orc.predict_merged(idx, lambda a, b: probs[a:a + b], T, 5, s, B)
+            lab = orc.labels_from_merged(merged, ml, xd, True)
+            want_rows = orc.segments(lab, 11)
+            assert np.array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1), want_rows), "record path != oracle post-processing"
+        got = pipe.run_batch(d_base, offs, lens, [11] * len(lens), list(range(len(lens))))
+        assert np.array_equal(got, np.concatenate(singles)), "batch != record path"
+    except Exception as e:      # noqa: BLE001
+        print("FAIL", tag, "->", repr(e), flush=True)
+        sys.exit(1)
+    m.close()
+    if it % 20 == 0:
+        print(f"{it} configurations ok, worst forward error {worst:.2e}", flush=True)
+print(f"done: {it} configurations ok, worst forward error {worst:.2e}")
