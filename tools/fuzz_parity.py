@@ -22,16 +22,25 @@ while time.time() < t_end:
     att = bool(rng.integers(0, 2))
     gain = float(rng.choice([0.5, 1.0, 2.0, 3.0]))
     ml, xd = [(50, 50), (3, 10), (10, 0), (0, -1), (1, 1)][int(rng.integers(0, 5))]
-    w = orc.Weights.random(u, 5, T, att, seed=int(rng.integers(0, 1 << 30)), gain=gain)
-    m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
-    pipe = ContigPipeline(m, s, B, ml, xd)
+    lstm = bool(rng.integers(0, 5) == 0) and u <= 128
+    use_mss = bool(rng.integers(0, 6) != 0)
+    if lstm:
+        att = False
+        w = orc.LSTMWeights.random(u, 5, T, seed=int(rng.integers(0, 1 << 30)), gain=min(gain, 2.0))
+        m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T, rnn="LSTM")
+    else:
+        w = orc.Weights.random(u, 5, T, att, seed=int(rng.integers(0, 1 << 30)), gain=gain)
+        m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    pipe = ContigPipeline(m, s, B, ml, xd, use_mss=use_mss)
     lens = [int(x) for x in rng.choice([1, 2, T, T + 1, T + s, 64, 65, 500, 3000, 9000], size=6)]
+    if rng.integers(0, 8) == 0:
+        lens[int(rng.integers(0, 6))] = int(rng.integers(50_000, 260_000))
     offs, pos = [], 0
     for n in lens:
         pos += int(rng.integers(0, 9)); offs.append(pos); pos += n
     base = rng.choice(5, size=pos + 3, p=[.24, .25, .25, .24, .02]).astype(np.uint8)
     d_base = torch.from_numpy(base).to(dev)
-    tag = f"it {it}: u={u} T={T} s={s} B={B} att={att} gain={gain} mss=({ml},{xd}) lens={lens}"
+    tag = f"it {it}: u={u} T={T} s={s} B={B} att={att} lstm={lstm} gain={gain} mss=({ml},{xd}) use_mss={use_mss} lens={lens}"
     try:
         singles = []
         for i, (o, n) in enumerate(zip(offs, lens)):
@@ -43,17 +52,18 @@ while time.time() < t_end:
             if nwin and n <= 3000:
                 nw = min(nwin, 24)
                 got = m.forward_windows(d_idx, s, 0, nw).cpu().numpy()
-                want = orc.nn_forward(idx, w, s, 0, nw, np.float64)
+                want = (orc.lstm_forward if lstm else orc.nn_forward)(idx, w, s, 0, nw, np.float64)
                 err = float(np.abs(got - want).max())
                 worst = max(worst, err)
                 assert err < 1e-3, f"forward error {err}"
             probs = m.forward_windows(d_idx, s, 0, nwin).cpu().numpy() if nwin else np.zeros((0, T, 5), np.float32)
             merged = orc.predict_merged(idx, lambda a, b: probs[a:a + b], T, 5, s, B)
-            lab = orc.labels_from_merged(merged, ml, xd, True)
+            lab = orc.labels_from_merged(merged, ml, xd, use_mss)
             want_rows = orc.segments(lab, 11)
             assert np.array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1), want_rows), "record path != oracle post-processing"
-        got = pipe.run_batch(d_base, offs, lens, [11] * len(lens), list(range(len(lens))))
-        assert np.array_equal(got, np.concatenate(singles)), "batch != record path"
+        if pipe.batchable():
+            got = pipe.run_batch(d_base, offs, lens, [11] * len(lens), list(range(len(lens))))
+            assert np.array_equal(got, np.concatenate(singles)), "batch != record path"
     except Exception as e:      # noqa: BLE001
         print("FAIL", tag, "->", repr(e), flush=True)
         sys.exit(1)
