@@ -78,7 +78,7 @@ def read_multi_fasta_file(path: Union[str, os.PathLike]) -> Iterator[Tuple[str, 
             chunk = mm[a:b]
             nl = chunk.find(b"\n")
             head, body = (chunk, b"") if nl == -1 else (chunk[:nl], chunk[nl + 1:])
-            if chunk.startswith(b">") and head.isascii() and _plain(body):
+            if chunk.startswith(b">") and head.isascii() and b"\r" not in head[:-1] and _plain(body):
                 # flush whatever the fallback loop still holds, then emit this record directly
                 if carry_header:
                     yield carry_header, "".join(carry_seq)
@@ -174,7 +174,12 @@ def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 25
                 while c1 < nchunks and c1 - c0 < group_records and starts[c1 + 1] - starts[c0] <= group_bytes:
                     c1 += 1
                 body0s = body0_all[c0:c1]
-                cand = [gt_all[c] and mm[starts[c]:head_ends[c]].isascii() for c in range(c0, c1)]
+                # fast path: starts with '>', ASCII header, and no carriage return inside the header line (text mode
+                # would end the line there; one directly before the line feed is just CRLF)
+                cand = []
+                for c in range(c0, c1):
+                    head = mm[starts[c]:head_ends[c]]
+                    cand.append(gt_all[c] and head.isascii() and b"\r" not in head[:-1])
                 g0, g1 = starts[c0], starts[c1]
                 infos = np.zeros((c1 - c0, 4), np.int64)
                 d_idx = None

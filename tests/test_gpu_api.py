@@ -352,6 +352,7 @@ def test_fasta_device_ingest_matches_reference_loop(orc, tmp_path):
         "empty_header.fa": ">a\nACGT\n>\nGG\n>c\nTT\n>onlyheader\n",
         "blank.fa": ">a\n" + wrap(seq(100)) + "\n\n>b\nAC\n",
         "lonecr.fa": ">a\nAC\rGT\n",
+        "cr_in_header.fa": ">h x\rACGT\n>b\nTT\n>c\rnn",          # text mode ends the header line at the lone CR
     }
     for name, text in files.items():
         path = tmp_path / name

@@ -389,7 +389,8 @@ def test_fast_fasta_reader_equals_reference_loop(tmp_path):
     cases = [">a\n" + wrap(seq(500)) + "\n>b desc\n" + wrap(seq(130)) + "\n", "junk\nACGT\n>a\n" + wrap(seq(100)) + "\n",
              ">a\r\n" + wrap(seq(200), 60, "\r\n") + "\r\n>b\r\nAC\r\n", ">a\n" + wrap(seq(100)) + "\n\n>b\nAC\n",
              ">a\nAC GT\n  >b\nTT\n>c\n\tGG \n", ">a\nACGT", ">a\nACGT\n>\nGG\n>c\nTT\n", ">a\n>b\n>c\nA\n", "",
-             ">only header\n", ">a\nAC\rGT\n", ">a\nACGT\n\n", "\n>a\nAC\n", ">a\n\xc3\xa4CGT\n"]
+             ">only header\n", ">a\nAC\rGT\n", ">a\nACGT\n\n", "\n>a\nAC\n", ">a\n\xc3\xa4CGT\n",
+             ">h\rnn", ">h x\rACGT\n>b\nTT\n", ">h\r\nAC\r\n", ">h\r"]
     for i, text in enumerate(cases):
         path = tmp_path / f"c{i}.fa"
         path.write_bytes(text.encode("latin-1"))
