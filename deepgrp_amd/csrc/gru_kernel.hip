@@ -136,6 +136,110 @@ __host__ __device__ static inline int gru_lds_dpart(int NW) { return 2 * NW * 64
 __host__ __device__ static inline int gru_lds_seq(int Tp) { return DGRP_WG_WINDOWS * Tp; }
 __host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 8 + DGRP_WG_WINDOWS * 4; }
 
+// ---- pieces shared by the GRU and the LSTM kernel --------------------------------------------------------------
+struct wg_ctx {                       // LDS carve of a workgroup and what its 16 windows are
+    _Float16 *hbuf;                   // [2][32][HS] hidden tile, ping-pong
+    float *dpart;                     // [2][4 regs][NW][64] partial logits of the waves
+    uint8_t *seqs;                    // [16][Tp] class indices of the windows
+    int64_t *row0s;                   // first output row of each window (mode 0: merged row, else row in [nw*T])
+    int *rowoff;                      // mode 0: row in the LDS image, -1 = goes to HBM directly
+    unsigned *obuf;                   // mode 0: max image of the rows the windows cover
+    int64_t wg_w, lo;                 // first window; first row of the image
+    int nvalid;
+};
+
+// carve, stage the windows' sequences, zero the state and the image, work out the placement (ends with a barrier)
+template <int NW, int MODE>
+__device__ __forceinline__ wg_ctx wg_setup(const gru_params &p, unsigned char *smem, int64_t bid)
+{
+    constexpr int UP = 32 * NW, HS = UP + 8;
+    wg_ctx c;
+    c.hbuf = reinterpret_cast<_Float16 *>(smem);
+    c.dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP));
+    c.seqs = smem + gru_lds_hbuf(UP) + gru_lds_dpart(NW);
+    c.row0s = reinterpret_cast<int64_t *>(c.seqs + gru_lds_seq(p.Tp));
+    c.rowoff = reinterpret_cast<int *>(c.row0s + DGRP_WG_WINDOWS);
+    c.obuf = reinterpret_cast<unsigned *>(c.rowoff + DGRP_WG_WINDOWS);
+    const int tid = threadIdx.x, T = p.T, C = p.C;
+    c.wg_w = p.w0 + bid * DGRP_WG_WINDOWS;
+    c.nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - c.wg_w);
+    for (int i = tid; i < DGRP_WG_WINDOWS * T; i += 64 * NW) {
+        const int wi = i / T, t = i - wi * T;
+        c.seqs[wi * p.Tp + t] = wi < c.nvalid ? p.idx[(c.wg_w + wi) * p.s + t] : (uint8_t)4;
+    }
+    for (int i = tid; i < 32 * HS; i += 64 * NW) c.hbuf[i] = (_Float16)0.0f;          // h_{-1} = 0
+    c.lo = 0;
+    if (MODE == 0) {
+        // smallest placement row of the two ends (the partial-batch shift keeps rows monotone inside
+        // each regime); windows that fall outside [lo, lo + ospan) go to HBM directly
+        const int64_t a = dgrp_place_row(p.place, c.wg_w, p.s), b = dgrp_place_row(p.place, c.wg_w + c.nvalid - 1, p.s);
+        c.lo = a < b ? a : b;
+        for (int i = tid; i < p.ospan * C; i += 64 * NW) c.obuf[i] = 0u;
+    }
+    if (tid < DGRP_WG_WINDOWS) {
+        int64_t r0 = -1;
+        int off = -1;
+        if (tid < c.nvalid) {
+            r0 = MODE == 0 ? dgrp_place_row(p.place, c.wg_w + tid, p.s) : (c.wg_w + tid - p.w0 + p.avgw) * (int64_t)T;
+            if (MODE == 0 && r0 >= c.lo && r0 - c.lo + T <= p.ospan) off = (int)(r0 - c.lo);
+        }
+        c.row0s[tid] = r0;
+        c.rowoff[tid] = off;
+    }
+    __syncthreads();
+    return c;
+}
+
+// merge (mode 0) or store one finished value of window `wi`, step t, class `cls`
+template <int MODE>
+__device__ __forceinline__ void emit_value(const gru_params &p, const wg_ctx &c, int off, int64_t row0, int t, int cls, float val)
+{
+    if (MODE == 0) {
+        if (off >= 0) {
+            lds_atomic_max(c.obuf + (off + t) * p.C + cls, __float_as_uint(val));
+        } else {
+            const int64_t row = row0 + t;
+            if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * p.C + cls, __float_as_uint(val));
+        }
+    } else {
+        p.out[(row0 + t) * p.C + cls] = val;
+    }
+}
+
+// Softmax + merge of step t's partial logits for accumulator register `reg`: the 16x16 logit tile (window =
+// 4*(lane>>4) + reg, class = lane & 15) is split by register over the waves, one value per lane.
+template <int NW, int MODE>
+__device__ __forceinline__ void finish_register(const gru_params &p, const wg_ctx &c, int t, int reg, float fbias, int off, int64_t row0)
+{
+    const int lane = threadIdx.x & 63, cls = lane & 15;
+    const float *dp = c.dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
+    float sum = dp[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) sum += dp[w * 64];
+    const int wi = 4 * (lane >> 4) + reg;
+    const float lg = cls < p.C ? sum + fbias : -INFINITY;
+    float val = lg;
+    if (MODE != 2) {                                  // attention: softmax happens in the second kernel
+        const float m = row_allmax(lg);
+        const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg - m));   // 0 for the padding lanes
+        val = e * __builtin_amdgcn_rcpf(row_allsum(e));
+    }
+    if (cls < p.C && wi < c.nvalid) emit_value<MODE>(p, c, off, row0, t, cls, val);
+}
+
+// flush the pre-merged image: contiguous rows -> 256-byte atomic wave-instructions
+template <int NW>
+__device__ __forceinline__ void flush_image(const gru_params &p, const wg_ctx &c)
+{
+    __syncthreads();
+    unsigned *gout = reinterpret_cast<unsigned *>(p.out) + c.lo * p.C;
+    const int64_t lim = (p.n - c.lo) * p.C;
+    for (int i = threadIdx.x; i < p.ospan * p.C; i += 64 * NW) {
+        const unsigned v = c.obuf[i];
+        if (v != 0u && i < lim) global_atomic_max(gout + i, v);
+    }
+}
+
 #ifdef DGRP_STAMP
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += (uint32_t)(now_ - stamp_prev); stamp_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -172,12 +276,6 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     // step) are then re-read from L2 every step (16 KB per wave-step, a few % of L2 bandwidth)
     constexpr bool ZSTREAM = NW > 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    _Float16 *hbuf = reinterpret_cast<_Float16 *>(smem);
-    float *dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP));       // [2][4 regs][NW][64]
-    uint8_t *seqs = smem + gru_lds_hbuf(UP) + gru_lds_dpart(NW);
-    int64_t *row0s = reinterpret_cast<int64_t *>(seqs + gru_lds_seq(p.Tp));
-    int *rowoff = reinterpret_cast<int *>(row0s + DGRP_WG_WINDOWS);
-    unsigned *obuf = reinterpret_cast<unsigned *>(rowoff + DGRP_WG_WINDOWS);
 
 #ifdef DGRP_STAMP
     const uint64_t stamp_entry = __builtin_amdgcn_s_memtime();
@@ -187,9 +285,6 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, C = p.C;
-    const int64_t wg_w = p.w0 + bid * DGRP_WG_WINDOWS;                  // first window of this workgroup
-    const int nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - wg_w);
-
     // ---- resident B fragments ------------------------------------------------------------
     const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
     half8 Bz[KS + 1], Br[KS + 1], Bg[KS + 1], Bxh, Bd_hi, Bd_lo;
@@ -205,30 +300,12 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 2) * 64]);
 
     // ---- stage sequences, placement rows, zero state ---------------------------------------
-    for (int i = tid; i < DGRP_WG_WINDOWS * T; i += 64 * NW) {
-        const int wi = i / T, t = i - wi * T;
-        seqs[wi * p.Tp + t] = wi < nvalid ? p.idx[(wg_w + wi) * p.s + t] : (uint8_t)4;
-    }
-    for (int i = tid; i < 32 * HS; i += 64 * NW) hbuf[i] = (_Float16)0.0f;          // h_{-1} = 0
-    int64_t lo = 0;
-    if (MODE == 0) {
-        // smallest placement row of the two ends (the partial-batch shift keeps rows monotone inside
-        // each regime); windows that fall outside [lo, lo + ospan) go to HBM directly
-        int64_t a = dgrp_place_row(p.place, wg_w, p.s), b = dgrp_place_row(p.place, wg_w + nvalid - 1, p.s);
-        lo = a < b ? a : b;
-        for (int i = tid; i < p.ospan * C; i += 64 * NW) obuf[i] = 0u;
-    }
-    if (tid < DGRP_WG_WINDOWS) {
-        int64_t r0 = -1;
-        int off = -1;
-        if (tid < nvalid) {
-            r0 = MODE == 0 ? dgrp_place_row(p.place, wg_w + tid, p.s) : (wg_w + tid - p.w0 + p.avgw) * (int64_t)T;
-            if (MODE == 0 && r0 >= lo && r0 - lo + T <= p.ospan) off = (int)(r0 - lo);
-        }
-        row0s[tid] = r0;
-        rowoff[tid] = off;
-    }
-    __syncthreads();
+    const wg_ctx ctx = wg_setup<NW, MODE>(p, smem, bid);
+    _Float16 *const hbuf = ctx.hbuf;
+    float *const dpart = ctx.dpart;
+    const uint8_t *const seqs = ctx.seqs;
+    const int64_t wg_w = ctx.wg_w;
+    const int nvalid = ctx.nvalid;
 
     const int r = lane & 31;            // recurrent row of this lane's A fragment
     const int wi_a = r & 15;            // its window
@@ -250,35 +327,11 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     // class = lane & 15) is split by accumulator register over the waves, one value per lane.
     // placement of the wave's first register (reg = wave) never changes: keep it out of the step loop
     const int pwi = 4 * (lane >> 4) + (wave & 3);
-    const int p_off = rowoff[pwi];
-    const int64_t p_row0 = row0s[pwi];
+    const int p_off = ctx.rowoff[pwi];
+    const int64_t p_row0 = ctx.row0s[pwi];
     auto finish_reg = [&](int t, int reg) {
-        const float *dp = dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
-        float sum = dp[0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) sum += dp[w * 64];
         const int wi = 4 * (lane >> 4) + reg;
-        const float lg = cls < C ? sum + fbias : -INFINITY;
-        float val = lg;
-        if (MODE != 2) {                                  // attention: softmax happens in the second kernel
-            const float m = row_allmax(lg);
-            const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg - m));   // 0 for the padding lanes
-            val = e * __builtin_amdgcn_rcpf(row_allsum(e));
-        }
-        if (cls < C && wi < nvalid) {
-            const int off = reg == wave ? p_off : rowoff[wi];
-            const int64_t row0 = reg == wave ? p_row0 : row0s[wi];
-            if (MODE == 0) {
-                if (off >= 0) {
-                    lds_atomic_max(obuf + (off + t) * C + cls, __float_as_uint(val));
-                } else {
-                    const int64_t row = row0 + t;
-                    if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
-                }
-            } else {
-                p.out[(row0 + t) * C + cls] = val;
-            }
-        }
+        finish_register<NW, MODE>(p, ctx, t, reg, fbias, reg == wave ? p_off : ctx.rowoff[wi], reg == wave ? p_row0 : ctx.row0s[wi]);
     };
     auto finish_step = [&](int t) {
         for (int reg = wave; reg < 4; reg += NW) finish_reg(t, reg);
@@ -318,18 +371,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
     };
     auto finish_commit = [&](int t) {
         const float val = MODE == 2 ? fs_lg : fs_e;
-        if (pr_on) {
-            if (MODE == 0) {
-                if (p_off >= 0) {
-                    lds_atomic_max(obuf + (p_off + t) * C + cls, __float_as_uint(val));
-                } else {
-                    const int64_t row = p_row0 + t;
-                    if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
-                }
-            } else {
-                p.out[(p_row0 + t) * C + cls] = val;
-            }
-        }
+        if (pr_on) emit_value<MODE>(p, ctx, p_off, p_row0, t, cls, val);
         for (int reg = wave + NW; reg < 4; reg += NW) finish_reg(t, reg);      // NW < 4: the wave's other registers
     };
     // Dense on this wave's 32 units of the hidden tile `hb`: rows r (window) and r+16 (its rc) accumulate
@@ -504,16 +546,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         finish_step(T - 1);
     }
 
-    if (MODE == 0 && p.ospan > 0) {
-        __syncthreads();
-        // flush the pre-merged image: contiguous rows -> 256-byte atomic wave-instructions
-        unsigned *gout = reinterpret_cast<unsigned *>(p.out) + lo * C;
-        const int64_t lim = (p.n - lo) * C;
-        for (int i = tid; i < p.ospan * C; i += 64 * NW) {
-            const unsigned v = obuf[i];
-            if (v != 0u && i < lim) global_atomic_max(gout + i, v);
-        }
-    }
+    if (MODE == 0 && p.ospan > 0) flush_image<NW>(p, ctx);
 #ifdef DGRP_STAMP
     if (p.stamps && lane == 0) {
         uint64_t *o = p.stamps + ((size_t)blockIdx.x * NW + wave) * 16;
@@ -539,19 +572,10 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;
     constexpr bool STREAM = NW > 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    _Float16 *hbuf = reinterpret_cast<_Float16 *>(smem);
-    float *dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP));
-    uint8_t *seqs = smem + gru_lds_hbuf(UP) + gru_lds_dpart(NW);
-    int64_t *row0s = reinterpret_cast<int64_t *>(seqs + gru_lds_seq(p.Tp));
-    int *rowoff = reinterpret_cast<int *>(row0s + DGRP_WG_WINDOWS);
-    unsigned *obuf = reinterpret_cast<unsigned *>(rowoff + DGRP_WG_WINDOWS);
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, C = p.C;
-    const int64_t wg_w = p.w0 + (int64_t)blockIdx.x * DGRP_WG_WINDOWS;
-    const int nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - wg_w);
 
     const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
     half8 Bi[KS + 1], Bf[KS + 1], Bc[KS + 1], Bo[KS + 1], Bd_hi, Bd_lo;
@@ -567,28 +591,10 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
     Bd_hi = __builtin_bit_cast(half8, mypack[(size_t)(4 * (KS + 1)) * 64]);
     Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(4 * (KS + 1) + 1) * 64]);
 
-    for (int i = tid; i < DGRP_WG_WINDOWS * T; i += 64 * NW) {
-        const int wi = i / T, t = i - wi * T;
-        seqs[wi * p.Tp + t] = wi < nvalid ? p.idx[(wg_w + wi) * p.s + t] : (uint8_t)4;
-    }
-    for (int i = tid; i < 32 * HS; i += 64 * NW) hbuf[i] = (_Float16)0.0f;
-    int64_t lo = 0;
-    if (MODE == 0) {
-        int64_t a = dgrp_place_row(p.place, wg_w, p.s), b = dgrp_place_row(p.place, wg_w + nvalid - 1, p.s);
-        lo = a < b ? a : b;
-        for (int i = tid; i < p.ospan * C; i += 64 * NW) obuf[i] = 0u;
-    }
-    if (tid < DGRP_WG_WINDOWS) {
-        int64_t r0 = -1;
-        int off = -1;
-        if (tid < nvalid) {
-            r0 = MODE == 0 ? dgrp_place_row(p.place, wg_w + tid, p.s) : (wg_w + tid - p.w0) * (int64_t)T;
-            if (MODE == 0 && r0 >= lo && r0 - lo + T <= p.ospan) off = (int)(r0 - lo);
-        }
-        row0s[tid] = r0;
-        rowoff[tid] = off;
-    }
-    __syncthreads();
+    const wg_ctx ctx = wg_setup<NW, MODE>(p, smem, blockIdx.x);
+    _Float16 *const hbuf = ctx.hbuf;
+    float *const dpart = ctx.dpart;
+    const uint8_t *const seqs = ctx.seqs;
 
     const int r = lane & 31, wi_a = r & 15, dir = r >> 4, khalf = lane >> 5;
     const uint8_t *myseq = seqs + wi_a * p.Tp;
@@ -602,31 +608,9 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
     const float fbias = cls < C ? p.ffb[cls] : 0.0f;
 
     auto finish_step = [&](int t) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            if (reg % NW != wave) continue;
-            const float *dp = dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
-            float sum = dp[0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) sum += dp[w * 64];
+        for (int reg = wave; reg < 4; reg += NW) {
             const int wi = 4 * (lane >> 4) + reg;
-            const float lg = cls < C ? sum + fbias : -INFINITY;
-            const float m = row_allmax(lg);
-            const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg - m));
-            const float val = e * __builtin_amdgcn_rcpf(row_allsum(e));
-            if (cls < C && wi < nvalid) {
-                if (MODE == 0) {
-                    const int off = rowoff[wi];
-                    if (off >= 0) {
-                        lds_atomic_max(obuf + (off + t) * C + cls, __float_as_uint(val));
-                    } else {
-                        const int64_t row = row0s[wi] + t;
-                        if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * C + cls, __float_as_uint(val));
-                    }
-                } else {
-                    p.out[(row0s[wi] + t) * C + cls] = val;
-                }
-            }
+            finish_register<NW, MODE>(p, ctx, t, reg, fbias, ctx.rowoff[wi], ctx.row0s[wi]);
         }
     };
 
@@ -682,15 +666,7 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
         _Float16 *tmp = hcur; hcur = hnxt; hnxt = tmp;
     }
     finish_step(T - 1);
-    if (MODE == 0 && p.ospan > 0) {
-        __syncthreads();
-        unsigned *gout = reinterpret_cast<unsigned *>(p.out) + lo * C;
-        const int64_t lim = (p.n - lo) * C;
-        for (int i = tid; i < p.ospan * C; i += 64 * NW) {
-            const unsigned v = obuf[i];
-            if (v != 0u && i < lim) global_atomic_max(gout + i, v);
-        }
-    }
+    if (MODE == 0 && p.ospan > 0) flush_image<NW>(p, ctx);
 }
 
 // ------------------------------------------------------------------------------------------
