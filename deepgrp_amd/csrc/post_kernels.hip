@@ -1185,14 +1185,43 @@ __device__ __forceinline__ bool seg_is_end(const int8_t *lab, int64_t i, int64_t
     return v != 0 && (i >= n - 2 || lab[i + 1] != v);
 }
 
-__global__ void __launch_bounds__(256) seg_count_kernel(const int8_t *__restrict__ lab, int64_t n, uint64_t *__restrict__ tilecnt)
+// marks (batched records only): bit0 first base of a record, bit1 its last base, bit2 its second-to-last base, bit3 padding
+__device__ __forceinline__ uint64_t seg_flags_batch(const int8_t *lab, const uint8_t *marks, int64_t i)
+{
+    const uint8_t m = marks[i];
+    const int8_t v = lab[i];
+    if ((m & 8) || v == 0) return 0;
+    // sequence.pyx:43-53 per record: the last base is always its own segment
+    const bool st = (m & 1) || (m & 2) || lab[i - 1] != v;
+    const bool en = (m & 2) || (m & 4) || lab[i + 1] != v;
+    return ((uint64_t)st << 32) + (uint64_t)en;
+}
+
+// start flag in the upper word, end flag in the lower one; one record (marks == NULL) or many side by side
+template <bool BATCH>
+__device__ __forceinline__ uint64_t seg_flags(const int8_t *lab, const uint8_t *marks, int64_t i, int64_t n)
+{
+    if (BATCH) return seg_flags_batch(lab, marks, i);
+    return ((uint64_t)seg_is_start(lab, i, n) << 32) + (uint64_t)seg_is_end(lab, i, n);
+}
+
+struct seg_records {                  // BATCH: where the records start, what to add to positions, their tags
+    const int64_t *start;
+    const int64_t *startpos;
+    const int32_t *contig;
+    int64_t nrec;
+};
+
+template <bool BATCH>
+__global__ void __launch_bounds__(256) seg_count_kernel(const int8_t *__restrict__ lab, const uint8_t *__restrict__ marks, int64_t n,
+                                                        uint64_t *__restrict__ tilecnt)
 {
     __shared__ uint64_t lds[4];
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
     uint64_t c = 0;
     for (int j = 0; j < 8; ++j) {
         const int64_t i = base + j * 256 + threadIdx.x;
-        if (i < n) c += ((uint64_t)seg_is_start(lab, i, n) << 32) + (uint64_t)seg_is_end(lab, i, n);
+        if (i < n) c += seg_flags<BATCH>(lab, marks, i, n);
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
@@ -1200,7 +1229,9 @@ __global__ void __launch_bounds__(256) seg_count_kernel(const int8_t *__restrict
     if (threadIdx.x == 0) tilecnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
 }
 
-__global__ void __launch_bounds__(256) seg_emit_kernel(const int8_t *__restrict__ lab, int64_t n, int64_t offset, int32_t contig,
+template <bool BATCH>
+__global__ void __launch_bounds__(256) seg_emit_kernel(const int8_t *__restrict__ lab, const uint8_t *__restrict__ marks, int64_t n,
+                                                       int64_t offset, int32_t contig, seg_records recs,
                                                        const uint64_t *__restrict__ tileoff, dgrp_segment *__restrict__ rec, int64_t cap)
 {
     __shared__ uint64_t lds[4];
@@ -1209,19 +1240,33 @@ __global__ void __launch_bounds__(256) seg_emit_kernel(const int8_t *__restrict_
     uint64_t f[8], s = 0;
     for (int j = 0; j < 8; ++j) {
         const int64_t i = base + j;
-        f[j] = i < n ? ((uint64_t)seg_is_start(lab, i, n) << 32) + (uint64_t)seg_is_end(lab, i, n) : 0;
+        f[j] = i < n ? seg_flags<BATCH>(lab, marks, i, n) : 0;
         s += f[j];
     }
     uint64_t ex = block_exclusive_scan(s, nullptr, lds) + tileoff[blockIdx.x];
     for (int j = 0; j < 8; ++j) {
         const int64_t i = base + j;
-        if (f[j] >> 32) {
-            const int64_t k = (int64_t)(ex >> 32);
-            if (k < cap) { rec[k].start = i + offset; rec[k].label = lab[i]; rec[k].contig = contig; }
-        }
-        if (f[j] & 1) {
-            const int64_t k = (int64_t)(ex & 0xffffffffull);
-            if (k < cap) rec[k].end = i + 1 + offset;
+        if (f[j]) {
+            int64_t off = offset;
+            int32_t tag = contig;
+            if (BATCH) {
+                // the record of position i: last r with start[r] <= i
+                int64_t lo = 0, hi = recs.nrec;
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (recs.start[mid] <= i) lo = mid; else hi = mid;
+                }
+                off = recs.startpos[lo] - recs.start[lo];
+                tag = recs.contig[lo];
+            }
+            if (f[j] >> 32) {
+                const int64_t k = (int64_t)(ex >> 32);
+                if (k < cap) { rec[k].start = i + off; rec[k].label = lab[i]; rec[k].contig = tag; }
+            }
+            if (f[j] & 1) {
+                const int64_t k = (int64_t)(ex & 0xffffffffull);
+                if (k < cap) rec[k].end = i + 1 + off;
+            }
         }
         ex += f[j];
     }
@@ -1293,8 +1338,7 @@ DGRP_EXPORT int dgrp_mss_labels_batch(const double *d_scores, const int8_t *d_cl
     return DGRP_OK;
 }
 
-// ---- batched records: padding fix-up of the score transform and the run-length extraction -----------------------
-// marks: bit0 first base of a record, bit1 its last base, bit2 its second-to-last base, bit3 padding
+// ---- batched records: padding fix-up of the score transform (marks: see seg_flags_batch) ------------------------
 __global__ void __launch_bounds__(64) rec_marks_kernel(const int64_t *__restrict__ start, const int64_t *__restrict__ len,
                                                        int64_t nrec, uint8_t *__restrict__ marks, double *__restrict__ scores,
                                                        int8_t *__restrict__ cls)
@@ -1315,71 +1359,6 @@ __global__ void __launch_bounds__(64) rec_marks_kernel(const int64_t *__restrict
         marks[i] = 8;
         if (scores) scores[i] = 0.0;
         if (cls) cls[i] = 0;
-    }
-}
-
-__device__ __forceinline__ uint64_t seg_flags_batch(const int8_t *lab, const uint8_t *marks, int64_t i)
-{
-    const uint8_t m = marks[i];
-    const int8_t v = lab[i];
-    if ((m & 8) || v == 0) return 0;
-    // sequence.pyx:43-53 per record: the last base is always its own segment
-    const bool st = (m & 1) || (m & 2) || lab[i - 1] != v;
-    const bool en = (m & 2) || (m & 4) || lab[i + 1] != v;
-    return ((uint64_t)st << 32) + (uint64_t)en;
-}
-
-__global__ void __launch_bounds__(256) seg_batch_count_kernel(const int8_t *__restrict__ lab, const uint8_t *__restrict__ marks,
-                                                              int64_t n, uint64_t *__restrict__ tilecnt)
-{
-    __shared__ uint64_t lds[4];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
-    uint64_t c = 0;
-    for (int j = 0; j < 8; ++j) {
-        const int64_t i = base + j * 256 + threadIdx.x;
-        if (i < n) c += seg_flags_batch(lab, marks, i);
-    }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) tilecnt[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
-}
-
-__global__ void __launch_bounds__(256) seg_batch_emit_kernel(const int8_t *__restrict__ lab, const uint8_t *__restrict__ marks,
-                                                             int64_t n, const int64_t *__restrict__ start, int64_t nrec,
-                                                             const int64_t *__restrict__ startpos, const int32_t *__restrict__ contig,
-                                                             const uint64_t *__restrict__ tileoff, dgrp_segment *__restrict__ rec,
-                                                             int64_t cap)
-{
-    __shared__ uint64_t lds[4];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * 8;
-    uint64_t f[8], s = 0;
-    for (int j = 0; j < 8; ++j) {
-        const int64_t i = base + j;
-        f[j] = i < n ? seg_flags_batch(lab, marks, i) : 0;
-        s += f[j];
-    }
-    uint64_t ex = block_exclusive_scan(s, nullptr, lds) + tileoff[blockIdx.x];
-    for (int j = 0; j < 8; ++j) {
-        const int64_t i = base + j;
-        if (f[j]) {
-            // the record of position i: last r with start[r] <= i
-            int64_t lo = 0, hi = nrec;
-            while (hi - lo > 1) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (start[mid] <= i) lo = mid; else hi = mid;
-            }
-            const int64_t off = startpos[lo] - start[lo];
-            if (f[j] >> 32) {
-                const int64_t k = (int64_t)(ex >> 32);
-                if (k < cap) { rec[k].start = i + off; rec[k].label = lab[i]; rec[k].contig = contig[lo]; }
-            }
-            if (f[j] & 1) {
-                const int64_t k = (int64_t)(ex & 0xffffffffull);
-                if (k < cap) rec[k].end = i + 1 + off;
-            }
-        }
-        ex += f[j];
     }
 }
 
@@ -1404,10 +1383,10 @@ int dgrp_batch_segments(const int8_t *d_labels, const uint8_t *d_marks, int64_t 
     const int64_t ntiles = (total_n + SCAN_TILE - 1) / SCAN_TILE;
     uint64_t *tiles = (uint64_t *)d_work;
     uint64_t *grand = tiles + ntiles + 1;
-    hipLaunchKernelGGL(seg_batch_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, d_marks, total_n, tiles);
+    hipLaunchKernelGGL(seg_count_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, d_marks, total_n, tiles);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, tiles, ntiles, grand);
-    hipLaunchKernelGGL(seg_batch_emit_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, d_marks, total_n, d_start,
-                       nrec, d_startpos, d_contig, tiles, d_records, cap);
+    hipLaunchKernelGGL(seg_emit_kernel<true>, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, d_marks, total_n, (int64_t)0,
+                       (int32_t)0, seg_records{ d_start, d_startpos, d_contig, nrec }, tiles, d_records, cap);
     hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1), 0, stream, grand, d_count);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
@@ -1436,12 +1415,12 @@ DGRP_EXPORT int dgrp_segments(const int8_t *d_labels, int64_t n, int64_t offset,
     const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     uint64_t *tiles = (uint64_t *)d_work;
     uint64_t *grand = tiles + ntiles + 1;
-    hipLaunchKernelGGL(seg_count_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, n, tiles);
+    hipLaunchKernelGGL(seg_count_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, (const uint8_t *)nullptr, n, tiles);
     DGRP_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, stream, tiles, ntiles, grand);
     DGRP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(seg_emit_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, n, offset, contig, tiles,
-                       d_records, cap);
+    hipLaunchKernelGGL(seg_emit_kernel<false>, dim3((unsigned)ntiles), dim3(256), 0, stream, d_labels, (const uint8_t *)nullptr, n, offset,
+                       contig, seg_records{ nullptr, nullptr, nullptr, 0 }, tiles, d_records, cap);
     DGRP_LAUNCH_CHECK();
     hipLaunchKernelGGL(seg_total_kernel, dim3(1), dim3(1), 0, stream, grand, d_count);
     DGRP_LAUNCH_CHECK();
