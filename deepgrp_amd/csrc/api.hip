@@ -69,6 +69,45 @@ static inline float h2f(uint16_t b)
     return (float)h;
 }
 
+// ---- fragment packing shared by the GRU and the LSTM constructor (layouts: gru_kernel.hip) -----------------------
+struct frag_writer {
+    std::vector<uint16_t> &pack;
+    int NF;
+    uint16_t &at(int w, int f, int l, int j) { return pack[(((size_t)w * NF + f) * 64 + l) * 8 + j]; }
+};
+
+// k-steps 0..KS-1 of one gate: lane l of wave w holds rows 16 ks + 8 (l >> 5) + j of column `col` (scaled by gs)
+static void pack_recurrent(frag_writer fw, int w, int l, int frag0, int KS, const float *rec, int ld, int col, int u, bool uok, float gs)
+{
+    for (int ks = 0; ks < KS; ++ks)
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * (l >> 5) + j;
+            fw.at(w, frag0 + ks, l, j) = (uok && k < u) ? f2h(gs * rec[(size_t)k * ld + col]) : 0;
+        }
+}
+
+// the input k-step: 8 values (5 kernel rows, bias, 2 x zero) as fp16 hi parts in lanes 0-31 and lo parts in lanes 32-63
+static void pack_input(frag_writer fw, int w, int l, int frag, const float v8[8])
+{
+    for (int j = 0; j < 8; ++j) {
+        const uint16_t hi = f2h(v8[j]);
+        fw.at(w, frag, l, j) = (l >> 5) == 0 ? hi : f2h(v8[j] - h2f(hi));
+    }
+}
+
+// Dense (16x16x32): 0.5 * FF kernel rows of this wave's 32 units (row offset `row0` for the avg half with attention)
+static void pack_dense(frag_writer fw, int w, int l, int frag_hi, int frag_lo, const float *ffk, int row0, int u, int C)
+{
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * (l >> 4) + j, du = 32 * w + k, c = l & 15;
+        float v = 0.0f;
+        if (du < u && c < C) v = 0.5f * ffk[(size_t)(row0 + du) * C + c];
+        const uint16_t hi = f2h(v);
+        fw.at(w, frag_hi, l, j) = hi;
+        fw.at(w, frag_lo, l, j) = f2h(v - h2f(hi));
+    }
+}
+
 DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *kernel,
                                   const float *rec, const float *bias, const float *scale, const float *ffk,
                                   const float *ffb)
@@ -119,7 +158,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     }
 
     std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
-    auto at = [&](int w, int f, int l, int j) -> uint16_t & { return pack[(((size_t)w * NF + f) * 64 + l) * 8 + j]; };
+    frag_writer fw{ pack, NF };
     for (int w = 0; w < m->NW; ++w) {
         for (int l = 0; l < 64; ++l) {
             const int unit = 32 * w + (l & 31);
@@ -128,47 +167,25 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
                 // exp2-domain scale folded into the weights: sigmoid(x) = 1/(1 + 2^(-x log2 e)) for z and r,
                 // tanh(x) = 1 - 2/(1 + 2^(2 x log2 e)) for the candidate (gru_kernel.hip)
                 const float gs = g < 2 ? -1.4426950408889634f : 2.8853900817779268f;
-                // recurrent part: k-steps 0..KS-1
-                for (int ks = 0; ks < KS; ++ks)
-                    for (int j = 0; j < 8; ++j) {
-                        const int k = 16 * ks + 8 * (l >> 5) + j;
-                        at(w, g * (KS + 1) + ks, l, j) = (uok && k < u) ? f2h(gs * rec[(size_t)k * u3 + g * u + unit]) : 0;
-                    }
-                // input part (k-step KS): rows 0-4 kernel hi, 5 bias hi | rows 8-12 kernel lo, 13 bias lo.
-                // z and r carry the whole input projection and both biases; the h gate's fragment only
-                // the RECURRENT bias (it sits inside r * (...)), its input projection is the Bxh fragment.
-                for (int j = 0; j < 8; ++j) {
-                    float v = 0.0f;
-                    if (uok) {
-                        if (j < 5) v = g < 2 ? kernel[(size_t)j * u3 + g * u + unit] : 0.0f;
-                        else if (j == 5) v = g < 2 ? (float)((double)bias[g * u + unit] + (double)bias[u3 + g * u + unit])
-                                                   : bias[u3 + 2 * u + unit];
-                    }
-                    v *= gs;
-                    if (m->onercp && g == 0 && j == 5 && uok) v += 1.0f;        // one-reciprocal blend wants 2 * 2^az
-                    const uint16_t hi = f2h(v);
-                    at(w, g * (KS + 1) + KS, l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
-                }
-            }
-            for (int j = 0; j < 8; ++j) {                                   // Bxh
-                float v = 0.0f;
+                pack_recurrent(fw, w, l, g * (KS + 1), KS, rec, u3, g * u + unit, u, uok, gs);
+                // input part (k-step KS): rows 0-4 kernel, 5 bias.  z and r carry the whole input projection and both
+                // biases; the h gate's fragment only the RECURRENT bias (it sits inside r * (...)), its input
+                // projection is the Bxh fragment.
+                float v8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
                 if (uok) {
-                    if (j < 5) v = kernel[(size_t)j * u3 + 2 * u + unit];
-                    else if (j == 5) v = bias[2 * u + unit];
+                    for (int j = 0; j < 5; ++j) v8[j] = g < 2 ? gs * kernel[(size_t)j * u3 + g * u + unit] : 0.0f;
+                    v8[5] = gs * (g < 2 ? (float)((double)bias[g * u + unit] + (double)bias[u3 + g * u + unit]) : bias[u3 + 2 * u + unit]);
+                    if (m->onercp && g == 0) v8[5] += 1.0f;                    // one-reciprocal blend wants 2 * 2^az
                 }
-                v *= 2.8853900817779268f;
-                const uint16_t hi = f2h(v);
-                at(w, 3 * (KS + 1), l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
+                pack_input(fw, w, l, g * (KS + 1) + KS, v8);
             }
-            // dense (16x16x32): 0.5 * FF kernel rows of this wave's 32 units; attention: the avg half
-            for (int j = 0; j < 8; ++j) {
-                const int k = 8 * (l >> 4) + j, du = 32 * w + k, c = l & 15;
-                float v = 0.0f;
-                if (du < u && c < C) v = 0.5f * ffk[(size_t)((attention ? u : 0) + du) * C + c];
-                const uint16_t hi = f2h(v);
-                at(w, 3 * (KS + 1) + 1, l, j) = hi;
-                at(w, 3 * (KS + 1) + 2, l, j) = f2h(v - h2f(hi));
+            float x8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };                          // Bxh
+            if (uok) {
+                for (int j = 0; j < 5; ++j) x8[j] = 2.8853900817779268f * kernel[(size_t)j * u3 + 2 * u + unit];
+                x8[5] = 2.8853900817779268f * bias[2 * u + unit];
             }
+            pack_input(fw, w, l, 3 * (KS + 1), x8);
+            pack_dense(fw, w, l, 3 * (KS + 1) + 1, 3 * (KS + 1) + 2, ffk, attention ? u : 0, u, C);
         }
     }
     float ffb16[16] = { 0 };
@@ -224,37 +241,22 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr;
     const int KS = m->KS, NF = m->nfrag, u4 = 4 * u;
     std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
-    auto at = [&](int w, int f, int l, int j) -> uint16_t & { return pack[(((size_t)w * NF + f) * 64 + l) * 8 + j]; };
+    frag_writer fw{ pack, NF };
     for (int w = 0; w < m->NW; ++w)
         for (int l = 0; l < 64; ++l) {
             const int unit = 32 * w + (l & 31);
             const bool uok = unit < u;
             for (int g = 0; g < 4; ++g) {
                 const float gs = g == 2 ? 2.8853900817779268f : -1.4426950408889634f;     // c: tanh, i/f/o: sigmoid
-                for (int ks = 0; ks < KS; ++ks)
-                    for (int j = 0; j < 8; ++j) {
-                        const int k = 16 * ks + 8 * (l >> 5) + j;
-                        at(w, g * (KS + 1) + ks, l, j) = (uok && k < u) ? f2h(gs * rec[(size_t)k * u4 + g * u + unit]) : 0;
-                    }
-                for (int j = 0; j < 8; ++j) {
-                    float v = 0.0f;
-                    if (uok) {
-                        if (j < 5) v = kernel[(size_t)j * u4 + g * u + unit];
-                        else if (j == 5) v = bias[g * u + unit];
-                    }
-                    v *= gs;
-                    const uint16_t hi = f2h(v);
-                    at(w, g * (KS + 1) + KS, l, j) = (l >> 5) == 0 ? hi : f2h(v - h2f(hi));
+                pack_recurrent(fw, w, l, g * (KS + 1), KS, rec, u4, g * u + unit, u, uok, gs);
+                float v8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                if (uok) {
+                    for (int j = 0; j < 5; ++j) v8[j] = gs * kernel[(size_t)j * u4 + g * u + unit];
+                    v8[5] = gs * bias[g * u + unit];
                 }
+                pack_input(fw, w, l, g * (KS + 1) + KS, v8);
             }
-            for (int j = 0; j < 8; ++j) {
-                const int k = 8 * (l >> 4) + j, du = 32 * w + k, c = l & 15;
-                float v = 0.0f;
-                if (du < u && c < C) v = 0.5f * ffk[(size_t)du * C + c];
-                const uint16_t hi = f2h(v);
-                at(w, 4 * (KS + 1), l, j) = hi;
-                at(w, 4 * (KS + 1) + 1, l, j) = f2h(v - h2f(hi));
-            }
+            pack_dense(fw, w, l, 4 * (KS + 1), 4 * (KS + 1) + 1, ffk, 0, u, C);
         }
     float ffb16[16] = { 0 };
     for (int c = 0; c < C; ++c) ffb16[c] = ffb[c];
