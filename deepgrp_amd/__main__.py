@@ -146,6 +146,7 @@ class CommandLineParser:
         from .distributed import gather_records, shard_contigs
         from .fasta import DeviceRecord, read_multi_fasta_device
         from .pipeline import SEGMENT_DTYPE, ContigPipeline, upload_sequence
+        from .runner import RecordRunner, rows_text, rows_text_batch
 
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
@@ -165,32 +166,6 @@ class CommandLineParser:
         if rank == 0:
             outstream = sys.stdout if args.output == "-" else open(args.output, "w")
 
-        def rows_text(filename: str, header: str, rows) -> str:
-            """The TSV rows of one record (__main__.py:291-292), built column-wise: integer -> text and the
-            concatenations are numpy loops, not one str.format per row."""
-            if len(rows) == 0:
-                return ""
-            prefix = "{}\t{}\t".format(filename, header)
-            cols = [rows[name].astype(np.int64).astype("U") for name in ("start", "end", "label")]
-            body = np.char.add(np.char.add(np.char.add(np.char.add(cols[0], "\t"), cols[1]), "\t"), cols[2])
-            return prefix + ("\n" + prefix).join(body.tolist()) + "\n"
-
-        def rows_text_batch(filename: str, headers, rows) -> str:
-            """The rows of a batch of records (rows["contig"] = index into `headers`), record order = row order."""
-            if len(rows) == 0:
-                return ""
-            prefixes = np.array(["{}\t{}\t".format(filename, h) for h in headers])[rows["contig"]]
-            cols = [rows[name].astype(np.int64).astype("U") for name in ("start", "end", "label")]
-            body = np.char.add(np.char.add(np.char.add(np.char.add(np.char.add(prefixes, cols[0]), "\t"), cols[1]), "\t"), cols[2])
-            return "\n".join(body.tolist()) + "\n"
-
-        def run_record(rec, contig=0):
-            if isinstance(rec, DeviceRecord):                 # parsed and encoded on the GPU
-                if rec.length < 0:
-                    raise ValueError("negative dimensions are not allowed")     # all-N record, sequence.pyx:32
-                return pipe.run_idx(rec.d_idx, rec.startpos, contig)
-            return pipe.run(rec, contig)
-
         def records_of(filename):
             if filename == "-" or not os.path.isfile(filename):
                 filestream = sys.stdin if filename == "-" else open(filename, "r")
@@ -202,100 +177,14 @@ class CommandLineParser:
             else:
                 yield from read_multi_fasta_device(filename)
 
-        def in_order(records, fn, workers: int = int(os.environ.get("DGRP_CLI_WORKERS", "16")), max_bases: int = 1 << 29):
-            """`fn(record)` for every (header, record) of the iterable on a small pool of threads, each with its own
-            HIP stream; yields (header, result) in input order.  Records are independent (__main__.py:280-292), so
-            while one is in its post-processing (whose fixed-point loop waits on the stream) the next ones are
-            already on the GPU, and a file of many short records no longer pays a launch-and-wait chain each.
-            The bases in flight are bounded; an exception surfaces where the sequential loop would raise it."""
-            import collections
-            import threading
-            from concurrent.futures import ThreadPoolExecutor
-            dev = torch.cuda.current_device() if torch.cuda.is_available() else None
-            local = threading.local()
-
-            def task(rec):
-                if dev is None:
-                    return fn(rec)
-                if not hasattr(local, "stream"):
-                    torch.cuda.set_device(dev)
-                    local.stream = torch.cuda.Stream()
-                with torch.cuda.stream(local.stream):
-                    out = fn(rec)
-                    local.stream.synchronize()
-                return out
-
-            def size(r):
-                if isinstance(r, list):
-                    return sum(x.length for _h, x in r)
-                return r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
-            pending: "collections.deque" = collections.deque()
-            inflight = 0
-            with ThreadPoolExecutor(max_workers=workers) as pool:
-                for header, rec in records:
-                    w = size(rec)
-                    while pending and (inflight + w > max_bases or len(pending) >= 4 * workers):
-                        h0, f0, w0 = pending.popleft()
-                        yield h0, f0.result()
-                        inflight -= w0
-                    pending.append((header, pool.submit(task, rec), w))
-                    inflight += w
-                    del rec
-                while pending:
-                    h0, f0, w0 = pending.popleft()
-                    yield h0, f0.result()
-
-        SMALL, BATCH_RECORDS, BATCH_BYTES = 1 << 18, 4096, 4 << 30
-        T_, UP_ = model.vecsize, (model.units + 31) // 32 * 32
-
-        def batch_cost(n: int) -> int:
-            """Workspace bytes a record of n bases adds to a batch (attention: the avg[t] spill of its windows dominates)."""
-            cost = 80 * n
-            if model.attention:
-                cost += len(range(0, n - T_, args.step_size)) * T_ * (UP_ * 2 + model.classes * 4)
-            return cost
-
-        def work_items(records):
-            """Consecutive short records of one ingest buffer become one item (a list), everything else stays single:
-            a batch goes through dgrp_predict_batch -- a handful of launches for thousands of records."""
-            group, bases = [], 0
-
-            def flush():
-                nonlocal group, bases
-                if group:
-                    yield "batch", group
-                group, bases = [], 0
-
-            for header, rec in records:
-                small = (pipe.batchable() and isinstance(rec, DeviceRecord) and rec.base is not None and 1 <= rec.length <= SMALL)
-                if small and group and (group[0][1].base is not rec.base or len(group) >= BATCH_RECORDS or bases + batch_cost(rec.length) > BATCH_BYTES):
-                    yield from flush()
-                if small:
-                    group.append((header, rec))
-                    bases += batch_cost(rec.length)
-                else:
-                    yield from flush()
-                    yield header, rec
-            yield from flush()
-
-        def run_item(item):
-            if isinstance(item, list):                        # a batch: rows of all its records, split per record afterwards
-                base = item[0][1].base
-                rows = pipe.run_batch(base, [r.offset for _h, r in item], [r.length for _h, r in item],
-                                      [r.startpos for _h, r in item], list(range(len(item))))
-                return [h for h, _r in item], rows
-            return run_record(item)
+        runner = RecordRunner(pipe)
 
         try:
             if world == 1:
                 for filename in args.FASTA:
                     _LOG.info("Processing %s", filename)
-                    for key, result in in_order(work_items(records_of(filename)), run_item):
-                        if key == "batch":
-                            headers, rows = result
-                            outstream.write(rows_text_batch(filename, headers, rows))
-                        else:
-                            outstream.write(rows_text(filename, key, result))
+                    for kind, key, rows in runner.results(records_of(filename)):
+                        outstream.write(rows_text_batch(filename, key, rows) if kind == "batch" else rows_text(filename, key, rows))
             else:
                 # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
                 records = []
@@ -321,13 +210,8 @@ class CommandLineParser:
                     mine = shard_contigs([length(r[2]) for r in records], world)[rank]
                     # this rank's share through the same pool / batching as the single-process path, keyed by record index
                     parts = []
-                    for key, result in in_order(work_items((i, records[i][2]) for i in mine), run_item):
-                        if key == "batch":
-                            ids, rows = result
-                            rows["contig"] = np.asarray(ids, np.int32)[rows["contig"]]
-                        else:
-                            rows = result
-                            rows["contig"] = key
+                    for kind, key, rows in runner.results((i, records[i][2]) for i in mine):
+                        rows["contig"] = np.asarray(key, np.int32)[rows["contig"]] if kind == "batch" else key
                         parts.append(rows)
                     local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
                     allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
