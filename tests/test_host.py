@@ -409,3 +409,64 @@ def test_fast_fasta_reader_equals_reference_loop(tmp_path):
                 yield from read_multi_fasta_lines(fh)
 
         assert run(lambda: read_multi_fasta_file(str(path))) == run(ref), f"case {i}: {text[:30]!r}"
+
+
+def test_record_runner_grouping_and_order():
+    """RecordRunner.work_items / in_order without a GPU: consecutive short device records of ONE ingest buffer form a
+    batch, anything else (other buffer, long record, text record, empty or all-N record) cuts it; results come back in
+    input order and an exception surfaces at its position."""
+    from deepgrp_amd.fasta import DeviceRecord
+    from deepgrp_amd import runner as rn
+
+    class FakeModel:
+        vecsize, units, classes, attention = 20, 32, 5, False
+
+    class FakePipe:
+        model, step = FakeModel(), 4
+        def batchable(self):
+            return True
+        def run_batch(self, base, offsets, lengths, startposes, contigs):
+            out = np.zeros(len(lengths), dtype=[("start", "<i8"), ("end", "<i8"), ("label", "<i4"), ("contig", "<i4")])
+            out["start"], out["end"], out["label"], out["contig"] = offsets, lengths, 1, contigs
+            return out
+        def run_idx(self, d_idx, startpos, contig=0):
+            return np.array([(startpos, startpos + 1, 2, contig)], dtype=[("start", "<i8"), ("end", "<i8"), ("label", "<i4"), ("contig", "<i4")])
+        def run(self, seq, contig=0):
+            if seq == "boom":
+                raise RuntimeError("boom")
+            return self.run_idx(None, len(seq), contig)
+
+    class Buf:                                              # stands in for a device tensor: only identity and slicing matter
+        def __getitem__(self, _s):
+            return self
+        def numel(self):
+            return 0
+
+    a, b = Buf(), Buf()
+    recs = [("r0", DeviceRecord(0, None, 100, a, 0)), ("r1", DeviceRecord(2, None, 50, a, 200)),
+            ("r2", DeviceRecord(0, None, 70, b, 0)),                          # other buffer: new batch
+            ("r3", "ACGT"),                                                   # text record: single
+            ("r4", DeviceRecord(0, None, 30, b, 100)), ("r5", DeviceRecord(0, None, rn.SMALL_RECORD + 1, b, 200)),   # long: single
+            ("r6", DeviceRecord(0, None, 0, b, 300)),                          # empty: single
+            ("r7", DeviceRecord(1, None, 10, b, 400)), ("r8", DeviceRecord(1, None, 10, b, 500))]
+    r = rn.RecordRunner(FakePipe(), workers=3)
+    items = list(r.work_items(recs))
+    shape = [(k, [kk for kk, _ in v]) if k == "batch" else (k, None) for k, v in items]
+    assert shape == [("batch", ["r0", "r1"]), ("batch", ["r2"]), ("r3", None), ("batch", ["r4"]), ("r5", None), ("r6", None),
+                     ("batch", ["r7", "r8"])]
+    out = list(r.results(recs))
+    assert [(kind, key) for kind, key, _rows in out] == [("batch", ["r0", "r1"]), ("batch", ["r2"]), ("one", "r3"), ("batch", ["r4"]),
+                                                          ("one", "r5"), ("one", "r6"), ("batch", ["r7", "r8"])]
+    assert out[0][2]["start"].tolist() == [0, 200] and out[0][2]["contig"].tolist() == [0, 1]
+    # an all-N record raises in place: everything before it is delivered first
+    bad = recs[:3] + [("n", DeviceRecord(4, None, -4, b, 0))] + recs[3:]
+    got = []
+    with pytest.raises(ValueError, match="negative dimensions"):
+        for kind, key, _rows in r.results(bad):
+            got.append(key)
+    assert got == [["r0", "r1"], ["r2"]]
+    with pytest.raises(RuntimeError, match="boom"):
+        list(r.results([("x", "ACGT"), ("y", "boom"), ("z", "AC")]))
+    # TSV text of a batch = the per-record texts one after the other
+    rows = out[0][2]
+    assert rn.rows_text_batch("f.fa", ["r0", "r1"], rows) == rn.rows_text("f.fa", "r0", rows[:1]) + rn.rows_text("f.fa", "r1", rows[1:])
