@@ -505,7 +505,7 @@ DGRP_EXPORT int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, in
     DGRP_REQUIRE(m && nrec >= 0 && s >= 1 && batch >= 1 && cap >= 0 && h_count, "dgrp_predict_batch: bad arguments");
     *h_count = 0;
     if (nrec == 0) return DGRP_OK;
-    DGRP_REQUIRE(m->cell == 0, "dgrp_predict_batch: GRU models only (use dgrp_predict_record)");
+    DGRP_REQUIRE(m->cell == 0 || (m->cell == 1 && m->NW <= 4), "dgrp_predict_batch: unsupported model");
     DGRP_REQUIRE(d_idx && h_idx_off && h_n && h_startpos && h_contig && d_work && (cap == 0 || d_records), "dgrp_predict_batch: NULL pointer");
     for (int64_t r = 0; r < nrec; ++r)
         DGRP_REQUIRE(h_n[r] >= 1 && h_idx_off[r] >= 0, "dgrp_predict_batch: record %lld: empty records do not belong in a batch", (long long)r);

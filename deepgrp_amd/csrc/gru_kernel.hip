@@ -148,6 +148,28 @@ struct wg_ctx {                       // LDS carve of a workgroup and what its 1
     int nvalid;
 };
 
+// batched records: rewrite the launch-wide parameters into those of the record this workgroup belongs to (last r with
+// wg_first[r] <= blockIdx.x; uniform over the workgroup: scalar loads) and return the workgroup's index inside it
+template <int MODE>
+__device__ __forceinline__ int64_t wg_record(const gru_params &pin, gru_params &p)
+{
+    if (MODE == 1 || !pin.recs) return blockIdx.x;
+    int64_t lo_r = 0, hi_r = pin.nrec;
+    while (hi_r - lo_r > 1) {
+        const int64_t mid = (lo_r + hi_r) >> 1;
+        if (pin.wg_first[mid] <= (int64_t)blockIdx.x) lo_r = mid; else hi_r = mid;
+    }
+    const gru_rec rc = pin.recs[lo_r];
+    p.idx = pin.idx + rc.idx_off;
+    p.n = rc.n;
+    if (MODE == 0) p.out = pin.out + rc.out_row * pin.C;
+    p.place = rc.place;
+    p.w0 = 0;
+    p.nw = rc.nwin;
+    p.avgw = rc.win_first;
+    return (int64_t)blockIdx.x - pin.wg_first[lo_r];
+}
+
 // carve, stage the windows' sequences, zero the state and the image, work out the placement (ends with a barrier)
 template <int NW, int MODE>
 __device__ __forceinline__ wg_ctx wg_setup(const gru_params &p, unsigned char *smem, int64_t bid)
@@ -252,24 +274,7 @@ template <int NW, int MODE, bool ONERCP>
 __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params pin)
 {
     gru_params p = pin;
-    int64_t bid = blockIdx.x;
-    if (MODE != 1 && pin.recs) {
-        // which record: last r with wg_first[r] <= blockIdx.x (uniform over the workgroup: scalar loads)
-        int64_t lo_r = 0, hi_r = pin.nrec;
-        while (hi_r - lo_r > 1) {
-            const int64_t mid = (lo_r + hi_r) >> 1;
-            if (pin.wg_first[mid] <= (int64_t)blockIdx.x) lo_r = mid; else hi_r = mid;
-        }
-        const gru_rec rc = pin.recs[lo_r];
-        bid = (int64_t)blockIdx.x - pin.wg_first[lo_r];
-        p.idx = pin.idx + rc.idx_off;
-        p.n = rc.n;
-        if (MODE == 0) p.out = pin.out + rc.out_row * pin.C;
-        p.place = rc.place;
-        p.w0 = 0;
-        p.nw = rc.nwin;
-        p.avgw = rc.win_first;
-    }
+    const int64_t bid = wg_record<MODE>(pin, p);
     constexpr bool PIPE = DGRP_PIPE;
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;   // HS: padded row pitch (halves) -> conflict-free b128 reads
     // u > 128: the three gate slices no longer fit 256 VGPRs; the z gate's fragments (needed last in a
@@ -567,8 +572,10 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 // then dense hi, dense lo.  Scales folded in: -log2 e for i, f, o; 2 log2 e for c.
 // ------------------------------------------------------------------------------------------
 template <int NW, int MODE>
-__global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params p)
+__global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params pin)
 {
+    gru_params p = pin;
+    const int64_t bid = wg_record<MODE>(pin, p);
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8;
     constexpr bool STREAM = NW > 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -591,7 +598,7 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
     Bd_hi = __builtin_bit_cast(half8, mypack[(size_t)(4 * (KS + 1)) * 64]);
     Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(4 * (KS + 1) + 1) * 64]);
 
-    const wg_ctx ctx = wg_setup<NW, MODE>(p, smem, blockIdx.x);
+    const wg_ctx ctx = wg_setup<NW, MODE>(p, smem, bid);
     _Float16 *const hbuf = ctx.hbuf;
     float *const dpart = ctx.dpart;
     const uint8_t *const seqs = ctx.seqs;
@@ -1167,7 +1174,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
                           int64_t nrec, int64_t total_groups, int mode, float *d_out, void *d_avg, hipStream_t stream)
 {
     if (nrec <= 0 || total_groups <= 0) return DGRP_OK;
-    DGRP_REQUIRE(m->cell == 0 && m->NW <= 8 && (mode == 0 || mode == 2), "dgrp_gru_launch_batch: GRU models only");
+    DGRP_REQUIRE(m->NW <= 8 && (mode == 0 || (mode == 2 && m->cell == 0)), "dgrp_gru_launch_batch: mode 0, or the GRU attention pre-pass");
     gru_params p;
     p.idx = d_idx; p.n = 0; p.s = s; p.w0 = 0; p.nw = 0; p.place = dgrp_placement{ 0, 0 };
     p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = (_Float16 *)d_avg;
@@ -1183,6 +1190,14 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T, fixed);
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
+    if (m->cell == 1) {
+        switch (m->NW) {
+        case 1: return launch_lstm<1>(p, total_groups, lds, stream);
+        case 2: return launch_lstm<2>(p, total_groups, lds, stream);
+        case 3: return launch_lstm<3>(p, total_groups, lds, stream);
+        default: return launch_lstm<4>(p, total_groups, lds, stream);
+        }
+    }
     switch (m->NW) {
     case 1: return launch_gru<1>(p, total_groups, lds, m->onercp != 0, stream);
     case 2: return launch_gru<2>(p, total_groups, lds, m->onercp != 0, stream);

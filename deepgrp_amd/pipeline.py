@@ -262,8 +262,8 @@ class ContigPipeline:
         return host.view(SEGMENT_DTYPE).copy()
 
     def batchable(self) -> bool:
-        """dgrp_predict_batch covers GRU models (with or without attention) on the MSS path."""
-        return self.use_mss and getattr(self.model, "rnn", "GRU") == "GRU" and self.event_log is None
+        """dgrp_predict_batch covers every model on the MSS path (the -m softmax is normalised per record)."""
+        return self.use_mss and self.event_log is None
 
     def run_batch(self, d_base: torch.Tensor, offsets, lengths, startposes, contigs) -> np.ndarray:
         """Segment records of MANY short records whose class indices lie in one device buffer (record r: `lengths[r]`

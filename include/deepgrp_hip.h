@@ -198,9 +198,9 @@ int dgrp_predict_record(const dgrp_model *m, const uint8_t *d_idx, int64_t n, in
                         void *stream);
 
 /* The same chain for a BATCH of short records in a handful of launches (a file of thousands of contigs): record r =
- * h_n[r] >= 1 class indices at d_idx + h_idx_off[r] (after N stripping, startpos h_startpos[r]); GRU models (with
- * or without attention; attention spills avg[t] of every window of the batch into the workspace, so batches are
- * small), MSS labels (the -m path and LSTM models go record by record).  One GRU launch covers the windows
+ * h_n[r] >= 1 class indices at d_idx + h_idx_off[r] (after N stripping, startpos h_startpos[r]); any model (attention
+ * spills avg[t] of every window of the batch into the workspace, so batches are small), MSS labels (the -m path goes
+ * record by record: its softmax subtracts the record's global maximum).  One GRU / LSTM launch covers the windows
  * of all records, the post-processing runs on the records laid side by side (64-aligned), one wave per record in
  * the MSS scan.  d_records receives the segments of all records in record order, then position order, `contig` =
  * h_contig[r]; *h_count as in dgrp_predict_record.  Synchronises the stream.  Rows (each record rounded up to 64)

@@ -88,3 +88,26 @@ def test_predict_batch_equals_record_by_record(dev, orc, u, T, s, B, att):
     np.testing.assert_array_equal(got, want)
     assert len(want) > len(lens)
     m.close()
+
+
+@pytest.mark.parametrize("u,T,s,B", [(48, 40, 7, 9), (128, 60, 13, 256), (100, 25, 3, 4)])
+def test_predict_batch_lstm(dev, orc, u, T, s, B):
+    """rnn = "LSTM" models through the batched path: identical rows to record by record."""
+    import torch
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel
+    w = orc.LSTMWeights.random(u, 5, T, seed=u, gain=2.0)
+    m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T, rnn="LSTM")
+    rng = np.random.default_rng(u)
+    lens = [1, T - 1, T, T + 1, 64, T + 16 * s, 2000] + [int(x) for x in rng.integers(1, 4000, 20)]
+    offs, pos = [], 0
+    for n in lens:
+        pos += int(rng.integers(0, 20)); offs.append(pos); pos += n
+    base = rng.choice(5, size=pos + 5, p=[.24, .25, .25, .24, .02]).astype(np.uint8)
+    d_base = torch.from_numpy(base).to(dev)
+    pipe = ContigPipeline(m, s, B, 4, 6)
+    assert pipe.batchable()
+    got = pipe.run_batch(d_base, offs, lens, [3] * len(lens), list(range(len(lens))))
+    want = np.concatenate([pipe.run_idx(d_base[o:o + n].clone(), 3, contig=i) for i, (o, n) in enumerate(zip(offs, lens))])
+    np.testing.assert_array_equal(got, want)
+    m.close()
+
