@@ -433,12 +433,60 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         auto hfrag = [&](int k) -> half8 { return ZSTREAM ? *reinterpret_cast<const half8 *>(arow + 16 * k) : af[ZSTREAM ? 0 : k]; };
         // the streamed z fragments: ZPF of them in flight, the first ones requested before the g chain (same box, u=256:
         // 8 deep 157 ms, 4 deep 116, 2 deep 105, 1 deep 104 per 5 Mbp -- spilled registers cost more than exposed latency)
-        constexpr int ZPF = NW >= 7 ? 2 : 4;                 // 224+ units spill: every register counts more than latency
+#ifndef DGRP_ZPF
+#define DGRP_ZPF (NW >= 7 ? 2 : 4)
+#endif
+        constexpr int ZPF = DGRP_ZPF;                        // 224+ units spill: every register counts more than latency
         uint4 zq[ZSTREAM ? ZPF : 1];
         if (ZSTREAM) {
 #pragma unroll
             for (int i = 0; i < ZPF; ++i) zq[i] = mypack[(size_t)i * 64];
         }
+      if (ZSTREAM) {
+        // Beyond 128 units: the r and the (streamed) z chain run interleaved k-step by k-step, so one z fragment is
+        // consumed per TWO MFMAs and a fragment requested ZPF k-steps ahead has twice the time to arrive from L2; the
+        // hidden tile's fragments are read once for both.  Then the g chain with both sigmoids in its gaps.
+        f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
+        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[KS], xa, zero16, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const half8 hf = hfrag(k);
+            const half8 bz = __builtin_bit_cast(half8, zq[ZSTREAM ? k % ZPF : 0]);
+            if (k + ZPF < KS) zq[ZSTREAM ? k % ZPF : 0] = mypack[(size_t)(k + ZPF) * 64];
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], hf, ar, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(bz, hf, az, 0, 0, 0);
+        }
+        f32x4 dpl = zero4;
+        if (t > 0) dpl = dense_issue(hcur, t - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t > 1) finish_step(t - 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[KS], xa, zero16, 0, 0, 0);
+        f32x2 rr[8], zz[8];
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], hfrag(k), ag, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 2 * (k * 8 / KS); i < 2 * ((k + 1) * 8 / KS); i += 2) {
+                rr[i / 2] = rcp1p_exp2_pair(ar[i], ar[i + 1]);
+                zz[i / 2] = rcp1p_exp2_pair(az[i], az[i + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {                                          // r * (h.U_h + b_rec_h)
+            const f32x2 pr = f32x2{ ag[i], ag[i + 1] } * rr[i / 2];
+            ag[i] = pr.x; ag[i + 1] = pr.y;
+        }
+        ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, ag, 0, 0, 0);            // + x.W_h + b_in_h
+        if (t > 0) dense_store(t - 1, dpl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 hh = 1.0f - 2.0f * rcp1p_exp2_pair(ag[2 * i], ag[2 * i + 1]);
+            h[i] = hh + zz[i] * (h[i] - hh);                                         // z*h + (1-z)*hh
+        }
+      } else {
         f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
         if (STAGED) finish_stage(0, t);                      // (steps 0 and 1 run the stages on stale data, uncommitted)
 #pragma unroll
@@ -518,6 +566,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
                 h[i] = hh[i] + z * (h[i] - hh[i]);                             // z*h + (1-z)*hh
             }
         }
+      }
         // ---- publish h_t (fp16) for the next step's B operand: a lane holds 4 x 4 consecutive units of
         // one row (transposed tile), i.e. four 8-byte stores
         _Float16 *wrow = hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
