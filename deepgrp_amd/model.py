@@ -200,59 +200,152 @@ def load_model(path: str, custom_objects: Optional[dict] = None):
     return model
 
 
-def keras_config(vecsize: int, units: int, classes: int, attention: bool, dropout: float = 0.25, rnn: str = "GRU") -> dict:
-    """The functional-model config ``create_model`` produces (layer list as in the reference's
-    tests/test_model.json), reduced to the keys this package reads back."""
-    layers: List[dict] = [
-        {"class_name": "InputLayer", "name": "input_1", "inbound_nodes": [],
-         "config": {"batch_input_shape": [None, vecsize, 5], "dtype": "float32", "sparse": False, "ragged": False, "name": "input_1"}},
-        {"class_name": "Custom>ReverseComplement", "name": "reverse_complement", "inbound_nodes": [[["input_1", 0, 0, {}]]],
-         "config": {"name": "reverse_complement", "trainable": True, "dtype": "float32", "complements": [3, 2, 1, 0, 4]}},
-        {"class_name": "GRU", "name": "BGRU",
-         "inbound_nodes": [[["input_1", 0, 0, {}]], [["reverse_complement", 0, 0, {}]]],
-         "config": {"name": "BGRU", "trainable": True, "dtype": "float32", "return_sequences": True, "return_state": bool(attention),
-                    "go_backwards": False, "stateful": False, "unroll": False, "time_major": False, "units": units,
-                    "activation": "tanh", "recurrent_activation": "sigmoid", "use_bias": True, "dropout": dropout,
-                    "recurrent_dropout": 0.0, "implementation": 2, "reset_after": True}},
-    ]
+# Keras names layers "<snake_case class>" then "<...>_1", "<...>_2" ... per process (InputLayer and Model count from
+# 1 / from the bare name); the reference's fixture tests/test_model.json records exactly those names.
+_LAYER_UIDS: Dict[str, int] = {}
+
+
+def reset_layer_names() -> None:
+    """What ``tf.keras.backend.clear_session()`` does to the name counters."""
+    _LAYER_UIDS.clear()
+
+
+def _unique_name(prefix: str, uids: Dict[str, int], first_is_bare: bool = True) -> str:
+    n = uids.get(prefix, 0)
+    uids[prefix] = n + 1
+    if first_is_bare:
+        return prefix if n == 0 else f"{prefix}_{n}"
+    return f"{prefix}_{n + 1}"
+
+
+def _functional_config(vecsize: int, units: int, classes: int, attention: bool, dropout: float, rnn: str,
+                       uids: Dict[str, int]) -> dict:
+    """``create_model(options).get_config()`` of the reference (deepgrp/model.py:293-336) as TensorFlow 2.5 -- the
+    version pinned in the reference's poetry.lock -- serialises it; equal to tests/test_model.json["2.5"] of the
+    reference key for key (tests/test_host.py)."""
+    def node(*sources):
+        return [[name, idx, tensor, {}] for name, idx, tensor in sources]
+
+    def plain(class_name, name, inbound, **extra):
+        return {"class_name": class_name, "config": {"name": name, "trainable": True, "dtype": "float32", **extra},
+                "name": name, "inbound_nodes": inbound}
+
+    rnn = rnn.upper()
+    attention = bool(attention) and rnn == "GRU"                 # deepgrp/model.py:308: attention only with the GRU
+    inp = _unique_name("input", uids, first_is_bare=False)
+    rc = _unique_name("reverse_complement", uids)
+    rname = "B" + rnn
+    rnn_cfg: Dict[str, Any] = {
+        "name": rname, "trainable": True, "dtype": "float32", "return_sequences": True, "return_state": attention,
+        "go_backwards": False, "stateful": False, "unroll": False, "time_major": False, "units": int(units),
+        "activation": "tanh", "recurrent_activation": "sigmoid", "use_bias": True,
+        "kernel_initializer": {"class_name": "GlorotUniform", "config": {"seed": None}, "shared_object_id": 2},
+        "recurrent_initializer": {"class_name": "Orthogonal", "config": {"gain": 1.0, "seed": None}, "shared_object_id": 3},
+        "bias_initializer": {"class_name": "Zeros", "config": {}, "shared_object_id": 4}}
     if rnn == "LSTM":
-        layers[2] = {"class_name": "LSTM", "name": "BLSTM",
-                     "inbound_nodes": [[["input_1", 0, 0, {}]], [["reverse_complement", 0, 0, {}]]],
-                     "config": {"name": "BLSTM", "trainable": True, "dtype": "float32", "return_sequences": True, "return_state": False,
-                                "go_backwards": False, "stateful": False, "unroll": False, "time_major": False, "units": units,
-                                "activation": "tanh", "recurrent_activation": "sigmoid", "use_bias": True, "unit_forget_bias": True,
-                                "dropout": dropout, "recurrent_dropout": 0.0, "implementation": 2}}
-        layers.append({"class_name": "Average", "name": "average", "config": {"name": "average"},
-                       "inbound_nodes": [[["BLSTM", 0, 0, {}], ["BLSTM", 1, 0, {}]]]})
-        last = "average"
-    elif attention:
-        layers += [
-            {"class_name": "Average", "name": "average", "config": {"name": "average"}, "inbound_nodes": [[["BGRU", 0, 1, {}], ["BGRU", 1, 1, {}]]]},
-            {"class_name": "Reshape", "name": "reshape", "config": {"name": "reshape", "target_shape": [1, units]}, "inbound_nodes": [[["average", 0, 0, {}]]]},
-            {"class_name": "Average", "name": "average_1", "config": {"name": "average_1"}, "inbound_nodes": [[["BGRU", 0, 0, {}], ["BGRU", 1, 0, {}]]]},
-            {"class_name": "AdditiveAttention", "name": "additive_attention", "config": {"name": "additive_attention", "causal": False, "dropout": 0.0, "use_scale": True},
-             "inbound_nodes": [[["reshape", 0, 0, {}], ["average_1", 0, 0, {}]]]},
-            {"class_name": "Flatten", "name": "flatten", "config": {"name": "flatten"}, "inbound_nodes": [[["additive_attention", 0, 0, {}]]]},
-            {"class_name": "RepeatVector", "name": "repeat_vector", "config": {"name": "repeat_vector", "n": vecsize}, "inbound_nodes": [[["flatten", 0, 0, {}]]]},
-            {"class_name": "Concatenate", "name": "concatenate", "config": {"name": "concatenate", "axis": -1},
-             "inbound_nodes": [[["repeat_vector", 0, 0, {}], ["average_1", 0, 0, {}]]]},
-        ]
-        last = "concatenate"
-    else:
-        layers.append({"class_name": "Average", "name": "average", "config": {"name": "average"},
-                       "inbound_nodes": [[["BGRU", 0, 0, {}], ["BGRU", 1, 0, {}]]]})
-        last = "average"
-    layers += [
-        {"class_name": "Dense", "name": "FF", "inbound_nodes": [[[last, 0, 0, {}]]],
-         "config": {"name": "FF", "trainable": True, "dtype": "float32", "units": classes, "activation": "linear", "use_bias": True}},
-        {"class_name": "Softmax", "name": "softmax", "config": {"name": "softmax", "axis": 2}, "inbound_nodes": [[["FF", 0, 0, {}]]]},
+        rnn_cfg["unit_forget_bias"] = True
+    rnn_cfg.update({"kernel_regularizer": None, "recurrent_regularizer": None, "bias_regularizer": None,
+                    "activity_regularizer": None, "kernel_constraint": None, "recurrent_constraint": None,
+                    "bias_constraint": None, "dropout": float(dropout), "recurrent_dropout": 0.0, "implementation": 2})
+    if rnn == "GRU":
+        rnn_cfg["reset_after"] = True
+    layers: List[dict] = [
+        {"class_name": "InputLayer",
+         "config": {"batch_input_shape": [None, int(vecsize), 5], "dtype": "float32", "sparse": False, "ragged": False, "name": inp},
+         "name": inp, "inbound_nodes": []},
+        plain("Custom>ReverseComplement", rc, [node((inp, 0, 0))], complements=_get_dna_encoding()),
+        {"class_name": rnn, "config": rnn_cfg, "name": rname, "inbound_nodes": [node((inp, 0, 0)), node((rc, 0, 0))]},
     ]
-    return {"class_name": "Functional", "config": {"name": "model", "layers": layers, "input_layers": [["input_1", 0, 0]],
-                                                  "output_layers": [["softmax", 0, 0]]}}
+    if attention:
+        hidden = _unique_name("average", uids)
+        reshape = _unique_name("reshape", uids)
+        avg = _unique_name("average", uids)
+        att = _unique_name("additive_attention", uids)
+        flat = _unique_name("flatten", uids)
+        rep = _unique_name("repeat_vector", uids)
+        last = _unique_name("concatenate", uids)
+        layers += [
+            plain("Average", hidden, [node((rname, 0, 1), (rname, 1, 1))]),
+            {"class_name": "Reshape", "config": {"name": reshape, "trainable": True, "batch_input_shape": [None, int(units)],
+                                                 "dtype": "float32", "target_shape": [1, int(units)]},
+             "name": reshape, "inbound_nodes": [node((hidden, 0, 0))]},
+            plain("Average", avg, [node((rname, 0, 0), (rname, 1, 0))]),
+            plain("AdditiveAttention", att, [node((reshape, 0, 0), (avg, 0, 0))], causal=False, use_scale=True, dropout=0.0),
+            plain("Flatten", flat, [node((att, 0, 0))], data_format="channels_last"),
+            plain("RepeatVector", rep, [node((flat, 0, 0))], n=int(vecsize)),
+            plain("Concatenate", last, [node((rep, 0, 0), (avg, 0, 0))], axis=-1),
+        ]
+    else:
+        last = _unique_name("average", uids)
+        layers.append(plain("Average", last, [node((rname, 0, 0), (rname, 1, 0))]))
+    soft = _unique_name("softmax", uids)
+    layers += [
+        plain("Dense", "FF", [node((last, 0, 0))], units=int(classes), activation="linear", use_bias=True,
+              kernel_initializer={"class_name": "GlorotUniform", "config": {"seed": None}},
+              bias_initializer={"class_name": "Zeros", "config": {}}, kernel_regularizer=None, bias_regularizer=None,
+              activity_regularizer=None, kernel_constraint=None, bias_constraint=None),
+        plain("Softmax", soft, [node(("FF", 0, 0))], axis=2),
+    ]
+    return {"name": _unique_name("model", uids), "layers": layers, "input_layers": [[inp, 0, 0]],
+            "output_layers": [[soft, 0, 0]]}
+
+
+def model_config(options: "Options") -> dict:
+    """``create_model(options).get_config()`` without building anything; layer names continue this process's
+    counters exactly as Keras' would (``reset_layer_names`` starts them over)."""
+    return _functional_config(options.vecsize, options.units, len(options.repeats_to_search) + 1, options.attention,
+                              options.dropout, options.rnn, _LAYER_UIDS)
+
+
+def keras_config(vecsize: int, units: int, classes: int, attention: bool, dropout: float = 0.25, rnn: str = "GRU") -> dict:
+    """The ``model_config`` attribute of a model file: the functional config under first-model-of-a-session names."""
+    return {"class_name": "Functional", "config": _functional_config(vecsize, units, classes, attention, dropout, rnn, {})}
+
+
+def initial_weights(options: "Options", seed: Optional[int] = None) -> Dict[str, Any]:
+    """Fresh tensors from the initialisers the config above names (Keras defaults: glorot_uniform kernels, orthogonal
+    recurrent kernel, zero biases -- ones for the LSTM forget gate --, glorot_uniform attention scale)."""
+    rng = np.random.default_rng(seed)
+    u, c = int(options.units), len(options.repeats_to_search) + 1
+    rnn = options.rnn.upper()
+    gates = 4 if rnn == "LSTM" else 3
+    attention = bool(options.attention) and rnn == "GRU"
+
+    def glorot(fan_in, fan_out, shape):
+        limit = np.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+    def orthogonal(rows, cols):
+        a = rng.standard_normal((max(rows, cols), min(rows, cols)))
+        q, r = np.linalg.qr(a)
+        q = q * np.sign(np.diag(r))
+        return (q.T if rows < cols else q).astype(np.float32)
+
+    if rnn == "LSTM":
+        bias = np.zeros(4 * u, np.float32)
+        bias[u:2 * u] = 1.0                                                    # unit_forget_bias
+    else:
+        bias = np.zeros((2, 3 * u), np.float32)
+    rows = (2 if attention else 1) * u
+    return dict(kernel=glorot(5, gates * u, (5, gates * u)), recurrent_kernel=orthogonal(u, gates * u), bias=bias,
+                ff_kernel=glorot(rows, c, (rows, c)), ff_bias=np.zeros(c, np.float32),
+                scale=glorot(u, u, (u,)) if attention else None, vecsize=int(options.vecsize), rnn=rnn)
+
+
+def create_model(options: "Options", seed: Optional[int] = None):
+    """Mirror of ``deepgrp.model.create_model`` (deepgrp/model.py:293-336) on the prediction side: a freshly
+    initialised, device-resident model of that architecture (``predict_on_batch``, ``get_config``, ``save``).
+    Training it is the reference's business (out of scope)."""
+    from .pipeline import DeviceModel
+    w = initial_weights(options, seed)
+    model = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"],
+                        vecsize=w["vecsize"], rnn=w["rnn"])
+    model.config = {"class_name": "Functional", "config": model_config(options)}
+    return model
 
 
 def save_keras_hdf5(path: str, kernel, recurrent_kernel, bias, ff_kernel, ff_bias, scale=None, vecsize: int = 200,
-                    rnn: str = "GRU") -> None:
+                    rnn: str = "GRU", config: Optional[dict] = None) -> None:
     """Write a model file in the layout ``model.save`` of the reference uses (root attribute
     ``model_config``; ``model_weights/<layer>/<weight name>`` datasets with ``weight_names``
     attributes).  Used for synthetic models in tests and benchmarks."""
@@ -263,11 +356,11 @@ def save_keras_hdf5(path: str, kernel, recurrent_kernel, bias, ff_kernel, ff_bia
     w = hdf5.Writer()
     w.set_attr("/", "keras_version", b"2.5.0")
     w.set_attr("/", "backend", b"tensorflow")
-    w.set_attr("/", "model_config", json.dumps(keras_config(vecsize, units, classes, attention, rnn=rnn)).encode("utf-8"))
+    config = config or keras_config(vecsize, units, classes, attention, rnn=rnn)
+    w.set_attr("/", "model_config", json.dumps(config).encode("utf-8"))
     rl, cell = ("BLSTM", "lstm_cell") if rnn == "LSTM" else ("BGRU", "gru_cell")
-    layer_names = ["input_1", "reverse_complement", rl] + (
-        ["average", "reshape", "average_1", "additive_attention", "flatten", "repeat_vector", "concatenate"] if attention else ["average"]
-    ) + ["FF", "softmax"]
+    layer_names = [layer["name"] for layer in config["config"]["layers"]]
+    att_name = next((l["name"] for l in config["config"]["layers"] if l["class_name"] == "AdditiveAttention"), None)
     w.create_group("model_weights")
     w.set_attr("model_weights", "layer_names", [n.encode() for n in layer_names])
     w.set_attr("model_weights", "backend", b"tensorflow")
@@ -276,7 +369,7 @@ def save_keras_hdf5(path: str, kernel, recurrent_kernel, bias, ff_kernel, ff_bia
                     (f"{rl}/{cell}/bias:0", bias)],
                "FF": [("FF/kernel:0", ff_kernel), ("FF/bias:0", ff_bias)]}
     if attention:
-        tensors["additive_attention"] = [("additive_attention/scale:0", np.asarray(scale, np.float32).reshape(-1))]
+        tensors[att_name] = [(f"{att_name}/scale:0", np.asarray(scale, np.float32).reshape(-1))]
     for lname in layer_names:
         w.create_group(f"model_weights/{lname}")
         items = tensors.get(lname, [])

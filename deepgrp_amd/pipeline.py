@@ -90,6 +90,26 @@ class DeviceModel:
     input_shape = property(lambda self: (None, self.vecsize, 5))
     output_shape = property(lambda self: (None, self.vecsize, self.classes))
 
+    # ---- the Keras model surface the reference touches besides predict_on_batch --------------------------------
+    def get_config(self) -> dict:
+        """``keras.Model.get_config()`` (tests/test_model.py:254-262 of the reference)."""
+        from . import model as dgmodel
+        if getattr(self, "config", None) is None:
+            self.config = dgmodel.keras_config(self.vecsize, self.units, self.classes, self.attention, rnn=self.rnn)
+        return self.config["config"]
+
+    def get_weights(self):
+        """Tensors in Keras' order: RNN kernel, recurrent kernel, bias, [attention scale], FF kernel, FF bias."""
+        scale = [] if self.scale is None else [self.scale.copy()]
+        return [self.kernel.copy(), self.recurrent_kernel.copy(), self.bias.copy()] + scale + [self.ff_kernel.copy(), self.ff_bias.copy()]
+
+    def save(self, path: str) -> None:
+        """``model.save("*.hdf5")`` (deepgrp/__main__.py:351): the Keras HDF5 layout ``load_model`` reads back."""
+        from . import model as dgmodel
+        self.get_config()
+        dgmodel.save_keras_hdf5(path, self.kernel, self.recurrent_kernel, self.bias, self.ff_kernel, self.ff_bias, self.scale,
+                                vecsize=self.vecsize, rnn=self.rnn, config=self.config)
+
     @property
     def kernel_flags(self) -> int:
         """dgrp_model_flags: bit 0 = the one-reciprocal GRU blend was provably safe for these weights."""

@@ -194,6 +194,41 @@ def test_load_model_and_predict_on_batch(orc, name):
     assert np.abs(got - orc.nn_forward(idx, w, T, 0, 9, np.float64)).max() < 1e-3
 
 
+@pytest.mark.parametrize("rnn", ("GRU", "LSTM"))
+def test_create_model(orc, tmp_path, rnn):
+    """tests/test_model.py:254-262 of the reference (config of a created model) plus what the reference does with
+    such a model afterwards: predict_on_batch, model.save, load_model."""
+    import json
+    with open(os.path.join(GOLDEN, "keras_model_config_tf25.json")) as fh:
+        expected = json.load(fh)["2.5"]
+    dgmodel.reset_layer_names()
+    if rnn == "LSTM":
+        dgmodel.model_config(dgmodel.Options(attention=True))             # the GRU model the reference built first
+    opts = dgmodel.Options(attention=True, rnn=rnn)
+    model = dgmodel.create_model(opts, seed=11)
+    assert json.loads(json.dumps(model.get_config())) == expected[rnn]
+    T = opts.vecsize
+    assert model.input_shape == (None, T, 5) and model.output_shape == (None, T, 5)
+    idx = np.random.default_rng(5).integers(0, 5, size=T * 7).astype(np.uint8)
+    batch = np.eye(5, dtype=np.float32)[idx].reshape(7, T, 5)
+    got = model.predict_on_batch(batch)
+    if rnn == "GRU":
+        k, r, b, sc, fk, fb = model.get_weights()
+        want = orc.nn_forward(idx, orc.Weights(k, r, b, fk, fb, sc, T), T, 0, 7, np.float64)
+    else:
+        k, r, b, fk, fb = model.get_weights()                              # attention is GRU-only (deepgrp/model.py:308)
+        want = orc.lstm_forward(idx, orc.LSTMWeights(k, r, b, fk, fb, T), T, 0, 7, np.float64)
+    assert np.abs(got - want).max() < 1e-3
+    path = str(tmp_path / "created.hdf5")
+    model.save(path)
+    again = dgmodel.load_model(path, custom_objects={"ReverseComplement": None})
+    assert again.get_config() == model.get_config()
+    np.testing.assert_array_equal(again.predict_on_batch(batch), got)
+    for a, b_ in zip(again.get_weights(), model.get_weights()):
+        np.testing.assert_array_equal(a, b_)
+    dgmodel.reset_layer_names()
+
+
 def _expected_tsv(orc, fasta_path, model_file, npz, step, B, ml, xd, use_mss):
     """What the reference CLI would print, computed by the oracle from the GPU's own probabilities."""
     from deepgrp_amd.pipeline import upload_sequence

@@ -144,6 +144,44 @@ def test_model_format_errors(tmp_path):
         dgmodel.read_keras_hdf5(str(tmp_path / "nocfg.h5"))
 
 
+def test_create_model_config_matches_the_reference_fixture():
+    """tests/test_model.py:254-262 of the reference: create_model(Options(attention=True, rnn=rnn)).get_config() equals
+    the stored config of its TensorFlow minor version -- 2.5 here, the version its poetry.lock pins (fixture copied
+    as data from tests/test_model.json).  Same order as the reference's parametrisation: the layer-name counters of
+    the second model continue those of the first."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "keras_model_config_tf25.json")) as fh:
+        expected = json.load(fh)["2.5"]
+    dgmodel.reset_layer_names()
+    for rnn in ("GRU", "LSTM"):
+        got = json.loads(json.dumps(dgmodel.model_config(dgmodel.Options(attention=True, rnn=rnn))))
+        assert got == expected[rnn], rnn
+    # a model file always carries first-of-a-session names, whatever was built before
+    cfg = dgmodel.keras_config(150, 32, 5, True)
+    assert cfg["class_name"] == "Functional" and cfg["config"] == expected["GRU"]
+    dgmodel.reset_layer_names()
+
+
+def test_initial_weights_follow_the_keras_initialisers():
+    for rnn, attention in (("GRU", True), ("GRU", False), ("LSTM", True)):
+        o = dgmodel.Options(units=24, vecsize=40, attention=attention, rnn=rnn)
+        w = dgmodel.initial_weights(o, seed=5)
+        g = 4 if rnn == "LSTM" else 3
+        att = attention and rnn == "GRU"
+        assert w["kernel"].shape == (5, g * 24) and w["recurrent_kernel"].shape == (24, g * 24)
+        assert np.abs(w["kernel"]).max() <= np.sqrt(6 / (5 + g * 24)) and np.abs(w["kernel"]).max() > 0.1
+        np.testing.assert_allclose(w["recurrent_kernel"] @ w["recurrent_kernel"].T, np.eye(24), atol=1e-5)   # orthogonal rows
+        assert w["ff_kernel"].shape == ((2 if att else 1) * 24, 5) and not w["ff_bias"].any()
+        if rnn == "LSTM":
+            assert w["scale"] is None and w["bias"].shape == (96,)
+            np.testing.assert_array_equal(w["bias"], np.r_[np.zeros(24), np.ones(24), np.zeros(48)])            # unit_forget_bias
+        else:
+            assert w["bias"].shape == (2, 72) and not w["bias"].any()
+            assert (w["scale"] is not None) == att
+        w2 = dgmodel.initial_weights(o, seed=5)
+        np.testing.assert_array_equal(w["kernel"], w2["kernel"])
+
+
 # ------------------------------------------------------------------------------------------ CLI
 class TestCommandLineParser:
     def test_init(self):
