@@ -157,7 +157,7 @@ class CommandLineParser:
             dist.init_process_group(os.environ.get("DGRP_DIST_BACKEND", "nccl"))
 
         _LOG.debug("Loading model %s!", args.model)
-        model = dgmodel.load_model(args.model, custom_objects={"ReverseComplement": None})
+        model = dgmodel.load_model(args.model, custom_objects={"ReverseComplement": dgmodel.ReverseComplement})
         options.vecsize = model.input_shape[1]
         _LOG.info("Model loading finished successfully!")
         pipe = ContigPipeline(model, args.step_size, options.batch_size, options.min_mss_len, options.xdrop_len,

@@ -98,6 +98,46 @@ def _get_dna_encoding() -> List[int]:
     return [v for _, v in sorted(complement.items())]
 
 
+class ReverseComplement:
+    """Mirror of the Keras layer ``deepgrp.model.ReverseComplement`` (deepgrp/model.py:240-290): reverse the time axis
+    of a one-hot batch [b, T, len(complements)] and gather the channel axis through ``complements``.  On the
+    prediction path the fused kernel reads the window backwards through the same table instead of materialising this
+    tensor; the class exists for callers that pass it as ``custom_objects`` or use it on arrays (numpy or torch)."""
+
+    def __init__(self, complements: List[int], name: Optional[str] = None, trainable: bool = True, dtype: str = "float32"):
+        self._indices = [int(c) for c in complements]
+        self._axis = [1]
+        self.name = name or "reverse_complement"
+        self.trainable, self.dtype = trainable, dtype
+        self.weights: List[Any] = []
+        self.trainable_weights: List[Any] = []
+
+    def build(self, input_shape) -> None:
+        return None
+
+    def call(self, inputs):
+        if hasattr(inputs, "flip"):                                        # torch tensor, any device
+            return inputs.flip(1)[:, :, self._indices]
+        return np.asarray(inputs)[:, ::-1, :][:, :, self._indices]
+
+    __call__ = call
+
+    def compute_mask(self, inputs, mask=None):
+        if mask is not None and not (isinstance(mask, (list, tuple)) and all(m is None for m in mask)):
+            raise TypeError(f"Layer {self.name} does not support masking, but was passed an input_mask: {mask}")
+        return None
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+    def get_config(self) -> Dict[str, Any]:
+        return {"name": self.name, "trainable": self.trainable, "dtype": self.dtype, "complements": list(self._indices)}
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "ReverseComplement":
+        return cls(**config)
+
+
 # --------------------------------------------------------------------------------------------
 # Keras HDF5
 # --------------------------------------------------------------------------------------------

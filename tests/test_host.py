@@ -144,6 +144,33 @@ def test_model_format_errors(tmp_path):
         dgmodel.read_keras_hdf5(str(tmp_path / "nocfg.h5"))
 
 
+def test_reverse_complement_layer():
+    """tests/test_model.py:182-251 of the reference: table, no weights, the 6x5 known answer, masking, serialisation."""
+    assert dgmodel._get_dna_encoding() == [3, 2, 1, 0, 4]
+    layer = dgmodel.ReverseComplement(complements=[3, 2, 1, 0, 4])
+    layer.build((1, 10, 5))
+    assert len(layer.trainable_weights) == 0 and len(layer.weights) == 0
+    input_data = np.array([[1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 0, 1, 0], [0, 0, 0, 0, 1],
+                           [1, 0, 0, 0, 0]]).reshape((1, -1, 5))
+    expected = np.array([[0, 0, 0, 1, 0], [0, 0, 0, 0, 1], [1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0],
+                         [0, 0, 0, 1, 0]]).reshape((1, -1, 5))
+    out = layer(input_data)
+    assert out.shape == (1, 6, 5)
+    np.testing.assert_equal(out, expected)
+    import torch
+    np.testing.assert_equal(layer(torch.from_numpy(input_data)).numpy(), expected)
+    assert layer.compute_mask(input_data, [None, None]) is None
+    with pytest.raises(TypeError, match="does not support masking, but was passed an input_mask"):
+        layer.compute_mask(input_data, input_data)
+    again = dgmodel.ReverseComplement.from_config(layer.get_config())
+    np.testing.assert_equal(again(input_data), expected)
+    assert layer.get_config() == {"name": "reverse_complement", "trainable": True, "dtype": "float32", "complements": [3, 2, 1, 0, 4]}
+    # applying it twice is the identity for a self-inverse table
+    rng = np.random.default_rng(0)
+    x = np.eye(5, dtype=np.float32)[rng.integers(0, 5, size=(3, 17))]
+    np.testing.assert_equal(layer(layer(x)), x)
+
+
 def test_create_model_config_matches_the_reference_fixture():
     """tests/test_model.py:254-262 of the reference: create_model(Options(attention=True, rnn=rnn)).get_config() equals
     the stored config of its TensorFlow minor version -- 2.5 here, the version its poetry.lock pins (fixture copied
