@@ -41,6 +41,14 @@ st, oh = orc.one_hot_encode_dna_sequence("NNACGTNNacgtXN")
 assert st == 2 and oh.shape == (5, 11)
 merged = orc.merge_all(np.random.default_rng(1).random((17, 20, 5), dtype=np.float32), 20 + 16 * 3, 3, 4)
 assert merged.shape == (68, 5)
+rng = np.random.default_rng(2)
+t, q = rng.integers(0, 5, size=5000), rng.integers(0, 5, size=5000)
+cnf = orc.confusion_matrix(t, q)
+assert cnf.sum() == 5000 and cnf[2, 3] == int(((t == 2) & (q == 3)).sum())
+lab = np.repeat(rng.integers(0, 3, size=400), rng.integers(1, 9, size=400))
+f = orc.filter_segments(lab, 5)
+assert f.shape == lab.shape and (f[lab == 0] == 0).all()
+assert orc.filter_segments(np.zeros(0, np.int64), 5).size == 0
 print("sanitized run ok")
 """
 
