@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--gain", type=float, default=3.0, help="weight scale of the random model")
     ap.add_argument("--cpu-sample-bp", type=int, default=400_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accuracy-windows", type=int, default=4096, help="windows compared with the fp32 yardstick after the run (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -164,6 +165,15 @@ def main():
                          "kernel": "gru_fused_kernel<4, 0, %s>" % ("true" if model.kernel_flags & 1 else "false"), "flop_per_window": FLOP_PER_WINDOW, "avg_launch_ms": round(avg_ms, 3),
                          "windows_per_launch": int(np.mean(kern_windows)), "launches_timed": len(kern_ms)},
         }
+        # how far the fp16-operand kernel is from a plain-fp32 evaluation of the same model on the device
+        # (ref_kernels.hip), on windows spread over this rank's chromosome; outside the timed region
+        acc = model.check_accuracy(d_idx, STEP, args.accuracy_windows) if args.accuracy_windows > 0 else None
+        if acc is not None:
+            out["accuracy"] = {"yardstick": "plain-fp32 HIP kernels (dgrp_forward_windows_reference), itself within 2e-5 of the float64 CPU statement",
+                               "windows": acc["windows_checked"], "median_window_max_abs_dp": round(acc["median_window_max"], 7),
+                               "q99_window_max_abs_dp": round(acc["q99_window_max"], 7), "max_abs_dp": round(acc["max_abs_diff"], 6),
+                               "frac_positions_above_1e-3": round(acc["positions_above_1e-3"] / acc["positions_checked"], 7),
+                               "argmax_flips": acc["argmax_flips"], "positions": acc["positions_checked"]}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample_bp)
         print(json.dumps(out), flush=True)

@@ -96,6 +96,16 @@ class CommandLineParser:
         predict.add_argument("FASTA", nargs="+", type=str, help="Fasta input files ('-' = stdin)")
         predict.add_argument("--output", type=str, default="-", help="Output filename")
         predict.add_argument("--no_use_mss", "-m", action="store_true", help="Disable maximum scoring segment algorithm")
+        verify = subparsers.add_parser(name="verify", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
+                                       description="(addition) measure how far the fp16-operand fused kernel is from a plain "
+                                                   "fp32 evaluation of the SAME model on the device, on windows of the given "
+                                                   "FASTA files (or a random sequence): the accuracy the 1e-3 bound is about")
+        verify.add_argument("model", type=str, help="Keras model in HDF5 format")
+        verify.add_argument("FASTA", nargs="*", type=str, help="Fasta input files; none = a random ACGT sequence")
+        verify.add_argument("--windows", type=int, default=256, help="windows to compare per record (spread evenly)")
+        predict.add_argument("--precise", action="store_true",
+                             help="(addition) run the forward pass in plain fp32 on the GPU instead of the fp16-operand fused "
+                                  "kernel: about 20x slower, class probabilities within ~1e-6 of an fp32 framework (see `verify`)")
         predict.add_argument("--split_contigs", action="store_true",
                              help="multi-GPU only: spread the windows of EVERY record over all GPUs (for a few huge "
                                   "records) instead of sharding whole records")
@@ -103,7 +113,7 @@ class CommandLineParser:
     def parse_args(self, argv=None) -> "CommandLineParser":
         argv = list(sys.argv[1:] if argv is None else argv)
         # README form `deepgrp <modelfile> <fastafile>`: insert the sub-command before the first positional
-        if not any(a in ("predict", "train") for a in argv):
+        if not any(a in ("predict", "train", "verify") for a in argv):
             takes_value = {"--batch_size", "-b", "--step_size", "-s", "--xdrop_length", "-x", "--min_mss_length", "-l",
                            "--threads", "-t"}
             i = 0
@@ -156,12 +166,14 @@ class CommandLineParser:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(os.environ.get("DGRP_DIST_BACKEND", "nccl"))
 
+        if getattr(args, "precise", False) and getattr(args, "split_contigs", False):
+            sys.exit("--precise is not combined with --split_contigs")
         _LOG.debug("Loading model %s!", args.model)
         model = dgmodel.load_model(args.model, custom_objects={"ReverseComplement": dgmodel.ReverseComplement})
         options.vecsize = model.input_shape[1]
         _LOG.info("Model loading finished successfully!")
         pipe = ContigPipeline(model, args.step_size, options.batch_size, options.min_mss_len, options.xdrop_len,
-                              use_mss=not args.no_use_mss)
+                              use_mss=not args.no_use_mss, precise=getattr(args, "precise", False))
         outstream = None
         if rank == 0:
             outstream = sys.stdout if args.output == "-" else open(args.output, "w")
@@ -224,6 +236,36 @@ class CommandLineParser:
             # interpreter shutdown)
             if rank == 0 and args.output != "-":
                 outstream.close()
+
+    @staticmethod
+    def verify(args: argparse.Namespace, options) -> None:
+        """One line per record: largest |p_fused - p_fp32| over the compared windows, and how many per-base argmax
+        calls differ.  Exit status 1 if any record exceeds 1e-3."""
+        from . import model as dgmodel
+        from .fasta import DeviceRecord, read_multi_fasta_device
+        from .pipeline import upload_sequence
+        model = dgmodel.load_model(args.model, custom_objects={"ReverseComplement": dgmodel.ReverseComplement})
+        results = []
+        if not args.FASTA:
+            results.append(("<random>", "ACGT", model.check_accuracy(None, args.step_size, args.windows)))
+        for filename in args.FASTA:
+            if filename == "-" or not os.path.isfile(filename):
+                stream = sys.stdin if filename == "-" else open(filename, "r")
+                records = list(_read_multi_fasta(stream))
+            else:
+                records = list(read_multi_fasta_device(filename))
+            for header, rec in records:
+                d_idx = rec.d_idx if isinstance(rec, DeviceRecord) else upload_sequence(rec.encode("utf-8"))[1]
+                if d_idx.numel() <= model.input_shape[1]:
+                    continue                                                # no window (prediction.py:31)
+                results.append((filename, header, model.check_accuracy(d_idx, args.step_size, args.windows)))
+        bad = False
+        for filename, header, r in results:
+            sys.stdout.write(f"{filename}\t{header}\t{r['max_abs_diff']:.3e}\t{r['windows_checked']}\t{r['argmax_flips']}\t"
+                             f"{'ok' if r['within_1e-3'] else 'ABOVE 1e-3'}\n")
+            bad = bad or not r["within_1e-3"]
+        if bad:
+            sys.exit(1)
 
     @staticmethod
     def train(args: argparse.Namespace, options) -> None:

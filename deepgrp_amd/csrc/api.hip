@@ -108,6 +108,30 @@ static void pack_dense(frag_writer fw, int w, int l, int frag_hi, int frag_lo, c
     }
 }
 
+// fp32 copies of the tensors as given (ref_kernels.hip reads them); one allocation, offsets in floats
+static hipError_t upload_raw(dgrp_model *m, const float *kernel, const float *rec, const float *bias, int64_t nbias,
+                             const float *ffk, int64_t nffk, const float *ffb, const float *scale)
+{
+    const int64_t G = m->cell ? 4 : 3, u = m->u;
+    std::vector<float> raw;
+    auto put = [&](const float *p, int64_t cnt) {
+        const int64_t off = (int64_t)raw.size();
+        if (p) raw.insert(raw.end(), p, p + cnt);
+        else raw.insert(raw.end(), (size_t)cnt, 0.0f);
+        raw.resize((raw.size() + 63) / 64 * 64, 0.0f);
+        return off;
+    };
+    m->raw_kernel = put(kernel, 5 * G * u);
+    m->raw_rec = put(rec, u * G * u);
+    m->raw_bias = put(bias, nbias);
+    m->raw_ffk = put(ffk, nffk);
+    m->raw_ffb = put(ffb, m->C);
+    m->raw_scale = put(scale, u);
+    hipError_t e = hipMalloc((void **)&m->d_raw, raw.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(m->d_raw, raw.data(), raw.size() * sizeof(float), hipMemcpyHostToDevice);
+    return e;
+}
+
 DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *kernel,
                                   const float *rec, const float *bias, const float *scale, const float *ffk,
                                   const float *ffb)
@@ -129,7 +153,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     m->NW = m->UP / 32;
     m->KS = m->UP / 16;
     m->nfrag = 3 * (m->KS + 1) + 3;
-    m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr;
+    m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
     const int KS = m->KS, NF = m->nfrag, u3 = 3 * u;
     // The update z*h + (1-z)*tanh(g) can be written with ONE reciprocal, of (1 + 2^az)(1 + 2^ag), if that
     // product cannot overflow: |h| <= 1 and 0 < r < 1 bound both pre-activations by the weights' absolute
@@ -215,6 +239,8 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
         CREATE_HIP(hipMalloc((void **)&m->d_wtop, wtop.size() * 4));
         CREATE_HIP(hipMemcpy(m->d_wtop, wtop.data(), wtop.size() * 4, hipMemcpyHostToDevice));
     }
+    CREATE_HIP(upload_raw(m, kernel, rec, bias, 2 * (int64_t)u3, ffk, (int64_t)(attention ? 2 : 1) * u * C, ffb,
+                          attention ? scale : nullptr));
 #undef CREATE_HIP
     *out = m;
     return DGRP_OK;
@@ -238,7 +264,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     m->NW = m->UP / 32;
     m->KS = m->UP / 16;
     m->nfrag = 4 * (m->KS + 1) + 2;
-    m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr;
+    m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
     const int KS = m->KS, NF = m->nfrag, u4 = 4 * u;
     std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
     frag_writer fw{ pack, NF };
@@ -264,6 +290,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     if (e == hipSuccess) e = hipMemcpy(m->d_pack, pack.data(), pack.size() * 2, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_ffb, sizeof(ffb16));
     if (e == hipSuccess) e = hipMemcpy(m->d_ffb, ffb16, sizeof(ffb16), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = upload_raw(m, kernel, rec, bias, u4, ffk, (int64_t)u * C, ffb, nullptr);
     if (e != hipSuccess) {
         dgrp_set_error("dgrp_model_create_lstm: %s", hipGetErrorString(e));
         dgrp_model_destroy(m);
@@ -280,6 +307,7 @@ DGRP_EXPORT int dgrp_model_destroy(dgrp_model *m)
     if (m->d_ffb) (void)hipFree(m->d_ffb);
     if (m->d_scale) (void)hipFree(m->d_scale);
     if (m->d_wtop) (void)hipFree(m->d_wtop);
+    if (m->d_raw) (void)hipFree(m->d_raw);
     delete m;
     return DGRP_OK;
 }

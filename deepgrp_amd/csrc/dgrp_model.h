@@ -15,6 +15,9 @@ struct dgrp_model {
     float *d_ffb;     // [16] dense bias, zero padded
     float *d_scale;   // [UP] attention scale (zero padded) or NULL
     float *d_wtop;    // [UP][16] rows of the dense kernel that multiply the context vector, or NULL
+    // the tensors as given, fp32, for the full-precision yardstick (ref_kernels.hip); offsets in floats into d_raw
+    float *d_raw;
+    int64_t raw_kernel, raw_rec, raw_bias, raw_ffk, raw_ffb, raw_scale;
 };
 
 // rows of LDS the fused kernel may use to pre-merge a workgroup's windows

@@ -136,6 +136,50 @@ class DeviceModel:
                                          _ptr(work), work.numel(), stream_ptr()), "dgrp_forward_windows")
         return probs
 
+    def forward_windows_reference(self, d_idx: torch.Tensor, step: int, w0: int, nw: int) -> torch.Tensor:
+        """The same windows through the plain-fp32 evaluation of the model on the device (dgrp_forward_windows_reference):
+        the yardstick the fused fp16-operand kernel is measured against.  Slow; hundreds of windows."""
+        probs = torch.empty((nw, self.vecsize, self.classes), dtype=torch.float32, device=d_idx.device)
+        wb = lib().dgrp_forward_reference_workspace_bytes(self.handle, nw)
+        work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
+        check(lib().dgrp_forward_windows_reference(self.handle, _ptr(d_idx), d_idx.numel(), step, w0, nw, _ptr(probs),
+                                                   _ptr(work), work.numel(), stream_ptr()), "dgrp_forward_windows_reference")
+        return probs
+
+    def check_accuracy(self, d_idx: Optional[torch.Tensor] = None, step: int = 50, windows: int = 256, seed: int = 0) -> dict:
+        """Largest deviation of the fused kernel's class probabilities from the fp32 yardstick on up to `windows`
+        windows spread evenly over the class-index tensor `d_idx` (default: a random ACGT sequence).  The bound the
+        path is built to is 1e-3 (BASELINE north star)."""
+        dev = require_gpu()
+        if d_idx is None:
+            rng = np.random.default_rng(seed)
+            d_idx = torch.from_numpy(rng.integers(0, 4, size=self.vecsize + step * windows, dtype=np.uint8)).to(dev)
+        total = int(lib().dgrp_window_count(d_idx.numel(), self.vecsize, step))
+        if total <= 0:
+            raise ValueError(f"sequence of {d_idx.numel()} bases holds no window of {self.vecsize}")
+        chunk = min(64, total)
+        starts = sorted({int(x) for x in np.linspace(0, total - chunk, max(1, min(windows, total) // chunk))})
+        worst, worst_window, checked, flips, above = 0.0, -1, 0, 0, 0
+        per_window = []
+        for w0 in starts:
+            fast = self.forward_windows(d_idx, step, w0, chunk)
+            ref = self.forward_windows_reference(d_idx, step, w0, chunk)
+            dpos = (fast - ref).abs().amax(dim=2)                           # [chunk, T]
+            diff = dpos.amax(dim=1)
+            per_window.append(diff)
+            k = int(diff.argmax())
+            if float(diff[k]) > worst:
+                worst, worst_window = float(diff[k]), w0 + k
+            flips += int((fast.argmax(dim=2) != ref.argmax(dim=2)).sum())
+            above += int((dpos > 1e-3).sum())
+            checked += chunk
+        pw = torch.cat(per_window).double()
+        q = torch.quantile(pw, torch.tensor([0.5, 0.99], dtype=torch.float64, device=pw.device)).cpu().numpy()
+        return {"max_abs_diff": worst, "window": worst_window, "windows_checked": checked, "argmax_flips": flips,
+                "positions_checked": checked * self.vecsize, "positions_above_1e-3": above,
+                "median_window_max": float(q[0]), "q99_window_max": float(q[1]),
+                "windows_above_1e-3": int((pw > 1e-3).sum()), "within_1e-3": worst <= 1e-3}
+
     def predict_on_batch(self, batch) -> np.ndarray:
         """Keras-style call on a one-hot batch [b, T, 5]; returns numpy float32 [b, T, C]."""
         dev = require_gpu()
@@ -171,7 +215,7 @@ class ContigPipeline:
     """Runs records through the device pipeline with the reference's CLI parameters."""
 
     def __init__(self, model: DeviceModel, step_size: int = 50, batch_size: int = 256, min_mss_len: int = 50,
-                 xdrop_len: int = 50, use_mss: bool = True, chunk_windows: int = 1 << 20):
+                 xdrop_len: int = 50, use_mss: bool = True, chunk_windows: int = 1 << 20, precise: bool = False):
         self.model = model
         self.step = int(step_size)
         self.batch = int(batch_size)
@@ -179,6 +223,9 @@ class ContigPipeline:
         self.xdrop_len = int(xdrop_len)
         self.use_mss = bool(use_mss)
         self.chunk_windows = int(chunk_windows)
+        # precise: the forward pass goes through the plain-fp32 kernels (ref_kernels.hip) instead of the fused fp16-operand
+        # kernel -- ~20x slower, probabilities within ~1e-6 of an fp32 framework (`predict --precise`)
+        self.precise = bool(precise)
         self.event_log = None        # bench.py: list collecting (start, end, windows) per GRU launch
         if self.step < 1 or self.batch < 1:
             raise ValueError("step_size and batch_size must be >= 1")
@@ -189,6 +236,25 @@ class ContigPipeline:
         n = d_idx.numel()
         out = torch.zeros((n, m.classes), dtype=torch.float32, device=d_idx.device)      # np.zeros, prediction.py:103
         nwin = L.dgrp_window_count(n, m.vecsize, self.step)
+        if self.precise:
+            # the reference's own loop (prediction.py:104-110): batches of B windows, batch i lands at row i * b * step
+            # (b = size of THAT batch); the forward pass runs for several batches at a time
+            B = self.batch
+            fit = (4 << 30) // (2 * m.vecsize * m.units * 4 + m.vecsize * (m.classes + 1) * 4)      # h_t of both strands, fp32
+            per = max(B, min(self.chunk_windows, fit) // B * B)
+            w0 = i = 0
+            while w0 < nwin:
+                nw = min(per, nwin - w0)
+                probs = m.forward_windows_reference(d_idx, self.step, w0, nw)
+                for off in range(0, nw, B):
+                    b = min(B, nw - off)
+                    index = i * b * self.step
+                    if index < n:
+                        check(L.dgrp_get_max(_ptr(out[index:]), n - index, _ptr(probs[off:off + b]), m.vecsize, m.classes,
+                                             self.step, b, stream_ptr()), "dgrp_get_max")
+                    i += 1
+                w0 += nw
+            return out
         chunk = self.chunk_windows
         if m.attention:
             # keep the avg[t] spill of one launch below ~2 GiB
@@ -259,7 +325,7 @@ class ContigPipeline:
     def run_idx(self, d_idx: torch.Tensor, startpos: int, contig: int = 0) -> np.ndarray:
         """Segment records of one record whose class indices are on the device: one dgrp_predict_record call
         (the staged merged -> labels -> segments path is kept for callers that time or inspect the stages)."""
-        if self.event_log is not None:
+        if self.event_log is not None or self.precise:
             return self.segments(self.labels(self.merged(d_idx)), startpos, contig)
         L = lib()
         n = d_idx.numel()
@@ -283,7 +349,7 @@ class ContigPipeline:
 
     def batchable(self) -> bool:
         """dgrp_predict_batch covers every model on the MSS path (the -m softmax is normalised per record)."""
-        return self.use_mss and self.event_log is None
+        return self.use_mss and self.event_log is None and not self.precise
 
     def run_batch(self, d_base: torch.Tensor, offsets, lengths, startposes, contigs) -> np.ndarray:
         """Segment records of MANY short records whose class indices lie in one device buffer (record r: `lengths[r]`

@@ -136,6 +136,15 @@ int dgrp_forward_merge(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int
                        int64_t batch, int64_t w0, int64_t nw, float *d_out, void *d_work,
                        int64_t work_bytes, void *stream);
 
+/* Accuracy yardstick (an addition; no counterpart in the reference, whose TensorFlow graph IS fp32): the same windows
+ * through a plain fp32 evaluation of deepgrp/model.py:293-336 on the device -- fp32 weights and state, expf/tanhf, no
+ * fp16, no MFMA -- so that the deviation of the fp16-operand fused kernel can be measured on the caller's own weights
+ * and sequence (`python -m deepgrp_amd verify`).  Slow (one workgroup per window and strand); meant for hundreds of
+ * windows.  Nothing on the prediction path calls it. */
+int64_t dgrp_forward_reference_workspace_bytes(const dgrp_model *m, int64_t nw);
+int dgrp_forward_windows_reference(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t w0,
+                                   int64_t nw, float *d_probs, void *d_work, int64_t work_bytes, void *stream);
+
 /* ---- A6 standalone: float *_get_max(float *output, float *inputs, size_t dim0, size_t dim1,
  * size_t stride, size_t batchsize)  (deepgrp/maxcalc.h:3-4).  Same argument meaning; buffers on
  * the device; out_rows bounds the writes (the reference has no bounds check). */

@@ -49,6 +49,7 @@ CASES = [
     ("dgrp_model_flags", lambda: (None,), "NULL model"),
     ("dgrp_forward_windows", lambda: (None, P, 1000, 50, 0, 1, P, P, 0, None), "dgrp_forward"),
     ("dgrp_forward_merge", lambda: (None, P, 1000, 50, 256, 0, 1, P, P, 0, None), "dgrp_forward"),
+    ("dgrp_forward_windows_reference", lambda: (None, P, 1000, 50, 0, 1, P, P, 1 << 20, None), "bad arguments"),
     ("dgrp_get_max", lambda: (P, 10, P, 0, 5, 5, 1, None), "bad shape"),
     ("dgrp_get_max", lambda: (P, 10, P, 2, 5, 0, 1, None), "bad shape"),
     ("dgrp_get_max", lambda: (None, 10, P, 2, 5, 5, 1, None), "NULL pointer"),

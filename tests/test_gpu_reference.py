@@ -1,0 +1,184 @@
+"""The fp32 yardstick on the device (ref_kernels.hip, `python -m deepgrp_amd verify`): a third statement of the forward
+pass, checked against the float64 oracle at oracle-feasible sizes and then used to check the fused kernel at sizes the
+CPU checker does not reach."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    return torch.device("cuda")
+
+
+def _idx(rng, n):
+    return rng.choice(5, size=n, p=[0.24, 0.25, 0.25, 0.24, 0.02]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("u,T,attention,gain,s,nw,C_", [
+    (128, 200, False, 1.0, 50, 24, 5), (128, 60, True, 2.0, 7, 20, 5), (60, 342, True, 1.0, 50, 6, 5),
+    (33, 40, False, 3.0, 5, 17, 3), (256, 50, True, 1.5, 25, 9, 5), (8, 20, True, 1.0, 2, 19, 16), (1, 10, False, 1.0, 1, 5, 2),
+])
+def test_reference_kernel_vs_oracle(dev, orc, u, T, attention, gain, s, nw, C_):
+    from deepgrp_amd.pipeline import DeviceModel
+    rng = np.random.default_rng(u * 7 + T)
+    w = orc.Weights.random(u, C_, T, attention, seed=5, gain=gain)
+    w.bias[:] = rng.normal(0, 0.2, size=w.bias.shape).astype(np.float32)
+    w.ff_bias[:] = rng.normal(0, 0.2, size=w.ff_bias.shape).astype(np.float32)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    idx = _idx(rng, T + s * (nw + 2))
+    got = dm.forward_windows_reference(torch.from_numpy(idx).to(dev), s, 1, nw).cpu().numpy()
+    want = orc.nn_forward(idx, w, s, 1, nw, np.float64)
+    assert np.abs(got - want).max() < 2e-5                       # fp32 vs float64 through T recurrent steps
+    fast = dm.forward_windows(torch.from_numpy(idx).to(dev), s, 1, nw).cpu().numpy()
+    assert np.abs(fast - got).max() < 1e-3
+    dm.close()
+
+
+@pytest.mark.parametrize("u,T,s,nw", [(128, 100, 25, 12), (24, 30, 7, 20), (96, 40, 10, 9)])
+def test_reference_kernel_lstm_vs_oracle(dev, orc, u, T, s, nw):
+    from deepgrp_amd.pipeline import DeviceModel
+    rng = np.random.default_rng(u)
+    w = orc.LSTMWeights.random(u, 5, T)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T, rnn="LSTM")
+    idx = _idx(rng, T + s * nw)
+    d = torch.from_numpy(idx).to(dev)
+    got = dm.forward_windows_reference(d, s, 0, nw).cpu().numpy()
+    assert np.abs(got - orc.lstm_forward(idx, w, s, 0, nw, np.float64)).max() < 2e-5
+    assert np.abs(dm.forward_windows(d, s, 0, nw).cpu().numpy() - got).max() < 1e-3
+    dm.close()
+
+
+def test_fused_kernel_vs_yardstick_at_bench_shape(dev):
+    """BASELINE configs[1] shape (u=128, T=200, s=50) on 2 048 windows of the benchmark's chromosome -- 30x what the
+    CPU checker covers in the parity tests.  Random-weight models (gain 3 = the edge of the validated envelope, and an
+    attention model) stay below 1e-3 everywhere.  The benchmark's fitted model does so on 99.7 % of the windows; it has
+    a few ill-conditioned ones (periodic repeats on which a 1e-7 perturbation of h is amplified 100x, reproduced in
+    numpy with nothing but fp16 rounding of the operands -- DESIGN.md 3.1 "Accuracy") where fp16 operands cost up to
+    a few 1e-3 here and up to 1e-1 on three windows of the whole 50 Mbp chromosome: that is what `predict --precise`
+    is for, and this test pins the distribution, not a wish."""
+    from deepgrp_amd import synthetic
+    from deepgrp_amd.pipeline import DeviceModel, upload_sequence
+    _st, d_idx = upload_sequence(synthetic.synthetic_chromosome(200 + 50 * 2048 + 1000, contig=0, flank=500))
+    cases = (("trained", synthetic.trained_weights(), None),
+             ("gain3", synthetic.synthetic_weights(128, 5, attention=False, seed=7, gain=3.0), 1e-3),
+             ("gain2att", synthetic.synthetic_weights(128, 5, attention=True, seed=9, gain=2.0), 1e-3))
+    for name, w, bound in cases:
+        dm = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=200)
+        r = dm.check_accuracy(d_idx, 50, 2048)
+        assert r["windows_checked"] == 2048 and r["positions_checked"] == 2048 * 200
+        if bound is not None:
+            assert r["max_abs_diff"] < bound and r["within_1e-3"], (name, r)
+        else:
+            assert r["median_window_max"] < 3e-4 and r["q99_window_max"] < 1e-3, r
+            assert r["windows_above_1e-3"] <= 20 and r["positions_above_1e-3"] <= 2048 * 200 // 1000, r
+            assert r["max_abs_diff"] < 2e-2 and r["argmax_flips"] <= 40, r
+        ref = dm.forward_windows_reference(d_idx, 50, 0, 256)
+        assert bool(torch.isfinite(ref).all()) and float((ref.sum(dim=2) - 1).abs().max()) < 1e-5
+        dm.close()
+
+
+def test_reference_entry_point_errors(dev, orc):
+    from deepgrp_amd._lib import lib
+    from deepgrp_amd.pipeline import DeviceModel
+    L = lib()
+    w = orc.Weights.random(16, 5, 30, False, seed=1)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=30)
+    idx = torch.zeros(200, dtype=torch.uint8, device=dev)
+    out = torch.full((4, 30, 5), 7.0, device=dev)
+    need = L.dgrp_forward_reference_workspace_bytes(dm.handle, 4)
+    work = torch.empty(need, dtype=torch.uint8, device=dev)
+    sp = torch.cuda.current_stream().cuda_stream
+    assert need >= 4 * 2 * 30 * 16 * 4
+    assert L.dgrp_forward_windows_reference(dm.handle, idx.data_ptr(), 200, 10, 0, 4, out.data_ptr(), work.data_ptr(), need - 1, sp) == -3
+    assert L.dgrp_forward_windows_reference(dm.handle, idx.data_ptr(), 200, 10, 16, 4, out.data_ptr(), work.data_ptr(), need, sp) == -1
+    assert "runs past" in L.dgrp_last_error().decode()
+    assert L.dgrp_forward_windows_reference(dm.handle, None, 200, 10, 0, 4, out.data_ptr(), work.data_ptr(), need, sp) == -1
+    assert L.dgrp_forward_windows_reference(None, idx.data_ptr(), 200, 10, 0, 4, out.data_ptr(), work.data_ptr(), need, sp) == -1
+    assert L.dgrp_forward_windows_reference(dm.handle, idx.data_ptr(), 200, 10, 0, 0, None, None, 0, sp) == 0
+    torch.cuda.synchronize()
+    assert bool((out == 7.0).all())
+    assert L.dgrp_forward_windows_reference(dm.handle, idx.data_ptr(), 200, 10, 0, 4, out.data_ptr(), work.data_ptr(), need, sp) == 0
+    torch.cuda.synchronize()
+    assert float((out.sum(dim=2) - 1).abs().max()) < 1e-5
+    with pytest.raises(ValueError, match="holds no window"):
+        dm.check_accuracy(torch.zeros(30, dtype=torch.uint8, device=dev), 10, 8)
+    dm.close()
+
+
+def test_cli_verify(tmp_path):
+    """`verify` prints one line per record with a window and exits 0 when all are within 1e-3."""
+    rng = np.random.default_rng(3)
+    fa = tmp_path / "v.fa"
+    seqs = ["".join(rng.choice(list("ACGT"), size=n)) for n in (5000, 342, 9000)]     # the middle one holds no window
+    fa.write_text("".join(f">r{i} x\n{s}\n" for i, s in enumerate(seqs)))
+    model = os.path.join(GOLDEN, "model_u60_T342_att.h5")
+    r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "verify", model, str(fa), "--windows", "64"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.split("\t") for l in r.stdout.strip().splitlines()]
+    assert [l[1] for l in lines] == ["r0 x", "r2 x"] and all(l[0] == str(fa) and l[5] == "ok" for l in lines)
+    assert all(0 < float(l[2]) < 1e-3 and int(l[3]) >= 64 for l in lines)
+    r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "verify", model], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("<random>\tACGT\t")
+
+
+# --------------------------------------------------------------------------------- precise mode (predict --precise)
+@pytest.mark.parametrize("u,T,attention,use_mss,B", [(64, 100, False, True, 256), (24, 60, True, True, 37), (32, 100, False, False, 100)])
+def test_precise_pipeline_vs_oracle(dev, orc, u, T, attention, use_mss, B):
+    """The whole path with the fp32 forward: merged probabilities within 2e-5 of the float64 statement driven by the
+    reference's own batch loop (partial last batch included), rows identical to the post-processing of
+    exactly those probabilities."""
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence
+    rng = np.random.default_rng(u + B)
+    w = orc.Weights.random(u, 5, T, attention, seed=3, gain=2.0)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    body = "".join(rng.choice(list("ACGT"), size=20011))
+    seq = "NNNN" + body[:7000] + "N" * 300 + body[7000:] + "NN"
+    pipe = ContigPipeline(dm, 50, B, 50, 50, use_mss, precise=True)
+    assert not pipe.batchable()
+    st, d_idx = upload_sequence(seq.encode())
+    idx = d_idx.cpu().numpy()
+    nwin = orc.window_count(idx.size, T, 50)
+    assert nwin % B != 0                                            # the partial last batch is exercised
+    merged = pipe.merged(d_idx).cpu().numpy()
+    want_merged = orc.predict_merged(idx, lambda a, b: orc.nn_forward(idx, w, 50, a, b, np.float64), T, 5, 50, B)
+    assert np.abs(merged - want_merged).max() < 2e-5
+    rows = pipe.run(seq, contig=1)
+    probs = dm.forward_windows_reference(d_idx, 50, 0, nwin).cpu().numpy()
+    want = orc.predict_contig(seq, lambda _idx: (lambda a, b: probs[a:a + b]), T, 5, 50, B, 50, 50, use_mss)
+    np.testing.assert_array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3), want)
+    # the fast path on a random-weight model (near-tie calls everywhere) differs in a handful of rows at most
+    fast = ContigPipeline(dm, 50, B, 50, 50, use_mss).run(seq, contig=1)
+    assert abs(len(fast) - len(rows)) <= max(3, len(rows) // 100)
+    dm.close()
+
+
+def test_cli_precise(tmp_path, orc):
+    rng = np.random.default_rng(8)
+    fa = tmp_path / "p.fa"
+    fa.write_text("".join(f">c{i}\n{''.join(rng.choice(list('ACGT'), size=n))}\n" for i, n in enumerate((6000, 100, 8000))))
+    model = os.path.join(GOLDEN, "model_u60_T342_att.h5")
+    outs = []
+    for extra in ([], ["--precise"]):
+        out = tmp_path / f"o{len(extra)}.tsv"
+        r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "predict", model, str(fa), "--output", str(out)] + extra,
+                           cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(out.read_text())
+    # the golden model's calls do not hinge on the fourth decimal: both modes print the same table
+    assert outs[0] == outs[1] and outs[0].count("\n") > 0
+    r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "predict", model, str(fa), "--precise", "--split_contigs"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--precise" in r.stderr

@@ -1,0 +1,34 @@
+"""Fast (fused fp16-operand kernel) against precise (plain-fp32 kernels) on a whole synthetic chromosome with the
+benchmark's model: distribution of the per-base probability deviation, label agreement, TSV rows, and the speed of
+both modes.  python tools/precise_vs_fast.py [Mbp] [trained|random]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deepgrp_amd import synthetic
+from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence
+
+mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 10
+kind = sys.argv[2] if len(sys.argv) > 2 else "trained"
+w = synthetic.trained_weights() if kind == "trained" else synthetic.synthetic_weights(128, 5, False, 7, 3.0)
+m = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=200)
+st, d_idx = upload_sequence(synthetic.synthetic_chromosome(int(mbp * 1e6)))
+fast, precise = ContigPipeline(m), ContigPipeline(m, precise=True)
+def T():
+    torch.cuda.synchronize(); return time.perf_counter()
+fast.merged(d_idx)
+t0 = T(); mf = fast.merged(d_idx); t1 = T(); mp = precise.merged(d_idx); t2 = T()
+print(f"{mbp:g} Mbp {kind}: fast forward+merge {1e3*(t1-t0):.1f} ms ({mbp/(t1-t0):.0f} Mbp/s), precise {1e3*(t2-t1):.1f} ms ({mbp/(t2-t1):.1f} Mbp/s)", flush=True)
+d = (mf - mp).abs().amax(dim=1)
+q = torch.quantile(d[:: max(1, d.numel() // 4_000_000)].double(), torch.tensor([0.5, 0.9, 0.99, 0.999, 0.9999], dtype=torch.float64, device=d.device)).cpu().numpy()
+print("per-base max|dp| of the merged probabilities: median %.2e  q90 %.2e  q99 %.2e  q99.9 %.2e  q99.99 %.2e  worst %.2e;  bases above 1e-3: %d of %d (%.4f %%)"
+      % (*q, float(d.max()), int((d > 1e-3).sum()), d.numel(), 100.0 * float((d > 1e-3).sum()) / d.numel()), flush=True)
+print("argmax differs on %d bases" % int((mf.argmax(dim=1) != mp.argmax(dim=1)).sum()))
+lf, lp = fast.labels(mf), precise.labels(mp)
+print("final labels differ on %d bases" % int((lf != lp).sum()))
+rf, rp = fast.segments(lf, st), precise.segments(lp, st)
+same = len(rf) == len(rp) and bool((rf == rp).all())
+print("TSV rows: fast %d, precise %d, identical: %s" % (len(rf), len(rp), same))
+if not same:
+    sf = {(int(a), int(b), int(c)) for a, b, c in zip(rf["start"], rf["end"], rf["label"])}
+    sp = {(int(a), int(b), int(c)) for a, b, c in zip(rp["start"], rp["end"], rp["label"])}
+    print("rows only in fast: %d, only in precise: %d; examples %s | %s" % (len(sf - sp), len(sp - sf), sorted(sf - sp)[:3], sorted(sp - sf)[:3]))
