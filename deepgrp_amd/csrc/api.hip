@@ -154,6 +154,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     m->KS = m->UP / 16;
     m->nfrag = 3 * (m->KS + 1) + 3;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
+    m->d_pack_lo = nullptr; m->precision = 0;
     const int KS = m->KS, NF = m->nfrag, u3 = 3 * u;
     // The update z*h + (1-z)*tanh(g) can be written with ONE reciprocal, of (1 + 2^az)(1 + 2^ag), if that
     // product cannot overflow: |h| <= 1 and 0 < r < 1 bound both pre-activations by the weights' absolute
@@ -241,6 +242,37 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     }
     CREATE_HIP(upload_raw(m, kernel, rec, bias, 2 * (int64_t)u3, ffk, (int64_t)(attention ? 2 : 1) * u * C, ffb,
                           attention ? scale : nullptr));
+    if (m->NW <= 4) {
+        // lo halves of the recurrent fragments for the split-operand kernel: what fp16 rounding dropped from the
+        // scaled weight, in the kernel's consumption order r, g, z
+        std::vector<uint16_t> lo((size_t)m->NW * 3 * KS * 64 * 8, 0);
+        static const int order[3] = { 1, 2, 0 };
+        for (int w = 0; w < m->NW; ++w)
+            for (int gi = 0; gi < 3; ++gi) {
+                const int g = order[gi];
+                const float gs = g < 2 ? -1.4426950408889634f : 2.8853900817779268f;
+                for (int ks = 0; ks < KS; ++ks)
+                    for (int l = 0; l < 64; ++l) {
+                        const int unit = 32 * w + (l & 31);
+                        for (int j = 0; j < 8; ++j) {
+                            const int k = 16 * ks + 8 * (l >> 5) + j;
+                            uint16_t v = 0;
+                            if (unit < u && k < u) {
+                                const float x = gs * rec[(size_t)k * u3 + g * u + unit];
+                                v = f2h(x - h2f(f2h(x)));
+                            }
+                            lo[((((size_t)w * 3 + gi) * KS + ks) * 64 + l) * 8 + j] = v;
+                        }
+                    }
+            }
+        CREATE_HIP(hipMalloc((void **)&m->d_pack_lo, lo.size() * 2));
+        CREATE_HIP(hipMemcpy(m->d_pack_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+        // Default for the models it covers: the split-operand kernel, the one that keeps every base within the 1e-3 of
+        // the north star whatever the model's conditioning.  dgrp_model_set_precision(m, 0) or
+        // DGRP_GRU_PRECISION=0 selects the 2.8x faster fp16-operand kernel.
+        const char *pe = getenv("DGRP_GRU_PRECISION");
+        m->precision = (!attention && !(pe && pe[0] == '0')) ? 1 : 0;
+    }
 #undef CREATE_HIP
     *out = m;
     return DGRP_OK;
@@ -265,6 +297,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     m->KS = m->UP / 16;
     m->nfrag = 4 * (m->KS + 1) + 2;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
+    m->d_pack_lo = nullptr; m->precision = 0;
     const int KS = m->KS, NF = m->nfrag, u4 = 4 * u;
     std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
     frag_writer fw{ pack, NF };
@@ -308,6 +341,7 @@ DGRP_EXPORT int dgrp_model_destroy(dgrp_model *m)
     if (m->d_scale) (void)hipFree(m->d_scale);
     if (m->d_wtop) (void)hipFree(m->d_wtop);
     if (m->d_raw) (void)hipFree(m->d_raw);
+    if (m->d_pack_lo) (void)hipFree(m->d_pack_lo);
     delete m;
     return DGRP_OK;
 }
@@ -325,7 +359,17 @@ DGRP_EXPORT int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int
 DGRP_EXPORT int dgrp_model_flags(const dgrp_model *m)
 {
     DGRP_REQUIRE(m, "dgrp_model_flags: NULL model");
-    return m->onercp ? 1 : 0;
+    return (m->onercp ? 1 : 0) | (m->precision == 1 ? 2 : 0);
+}
+
+DGRP_EXPORT int dgrp_model_set_precision(dgrp_model *m, int level)
+{
+    DGRP_REQUIRE(m, "dgrp_model_set_precision: NULL model");
+    DGRP_REQUIRE(level == 0 || level == 1, "dgrp_model_set_precision: level must be 0 (fp16 operands) or 1 (split operands)");
+    DGRP_REQUIRE(level == 0 || (m->cell == 0 && !m->attention && m->d_pack_lo),
+                 "dgrp_model_set_precision: the split-operand kernel covers GRU models without attention up to 128 units");
+    m->precision = level;
+    return DGRP_OK;
 }
 
 // attention keeps avg[t] (fp16 [nw,T,UP]) and the avg half of the logits (fp32 [nw,T,C]) between kernels

@@ -68,6 +68,11 @@ struct gru_params {
     const int64_t *wg_first;
     int64_t nrec;
     int64_t avgw;         // modes 1, 2: row of window w0 in the output / spill buffers (batched records: the record's first)
+    // split-operand kernel only: the lo halves of the recurrent fragments ([NW][3 KS][64] in the order r, g, z), the byte
+    // offset of the lo hidden tiles in the dynamic LDS, and 1.0 if the packed z bias carries the one-reciprocal "+1"
+    const uint4 *pack_lo;
+    int lo_tile_off;
+    float zfold;
 };
 
 // The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
@@ -612,6 +617,152 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 #endif
 }
 
+// ---- split-operand variant (dgrp_model_set_precision(m, 1)) -------------------------------------------------------
+// Same decomposition, but both MFMA operands of the recurrent contraction carry fp32-grade precision as fp16 pairs:
+// U = U_hi + U_lo (packed once), h_{t-1} = h_hi + h_lo (two LDS tiles), and  U.h ~ U_hi.h_hi + U_hi.h_lo + U_lo.h_hi
+// (the dropped U_lo.h_lo term is below 2^-22 of the product).  Three MFMAs per k-step instead of one: the matrix pipe,
+// half idle in the fast kernel, becomes the bound.  U_hi stays resident in VGPRs; the U_lo fragments stream from L2
+// every step through a 4-deep register ring in consumption order (r, g, z); the hidden tile's fragments are re-read
+// from LDS at every use.  Dense takes the lo tile too.  Written for correctness first: no staging of the softmax into
+// MFMA gaps, two reciprocals.  GRU without attention, up to 128 units.
+template <int NW, int MODE>
+__global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params pin)
+{
+    gru_params p = pin;
+    const int64_t bid = wg_record<MODE>(pin, p);
+    constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8, NLO = 3 * KS, PF = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, C = p.C;
+    const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
+    const uint4 *mylo = p.pack_lo + (size_t)wave * NLO * 64 + lane;
+    half8 Bz[KS + 1], Br[KS + 1], Bg[KS + 1], Bxh, Bd_hi, Bd_lo;
+#pragma unroll
+    for (int k = 0; k <= KS; ++k) {
+        Bz[k] = __builtin_bit_cast(half8, mypack[(size_t)(k) * 64]);
+        Br[k] = __builtin_bit_cast(half8, mypack[(size_t)(KS + 1 + k) * 64]);
+        Bg[k] = __builtin_bit_cast(half8, mypack[(size_t)(2 * (KS + 1) + k) * 64]);
+    }
+    Bxh = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1)) * 64]);
+    Bd_hi = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 1) * 64]);
+    Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 2) * 64]);
+
+    _Float16 *const lbuf = reinterpret_cast<_Float16 *>(smem + p.lo_tile_off);          // [2][32][HS] lo tiles
+    for (int i = tid; i < 32 * HS; i += 64 * NW) lbuf[i] = (_Float16)0.0f;
+    const wg_ctx ctx = wg_setup<NW, MODE>(p, smem, bid);                                  // ends with a barrier
+    float *const dpart = ctx.dpart;
+
+    const int r = lane & 31, wi_a = r & 15, dir = r >> 4, khalf = lane >> 5;
+    const uint8_t *myseq = ctx.seqs + wi_a * p.Tp;
+    f32x2 h[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = f32x2{ 0.0f, 0.0f };
+    _Float16 *hcur = ctx.hbuf, *hnxt = ctx.hbuf + 32 * HS, *lcur = lbuf, *lnxt = lbuf + 32 * HS;
+    const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const f32x4 zero4 = { 0, 0, 0, 0 };
+    const int cls = lane & 15;
+    const float fbias = cls < C ? p.ffb[cls] : 0.0f;
+    auto finish_step = [&](int t) {
+        for (int reg = wave; reg < 4; reg += NW) {
+            const int wi = 4 * (lane >> 4) + reg;
+            finish_register<NW, MODE>(p, ctx, t, reg, fbias, ctx.rowoff[wi], ctx.row0s[wi]);
+        }
+    };
+    const int doff = (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
+    auto dense_issue = [&](const _Float16 *hb, const _Float16 *lb) -> f32x4 {
+        const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff), a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
+        const half8 l0 = *reinterpret_cast<const half8 *>(lb + doff), l1 = *reinterpret_cast<const half8 *>(lb + doff + 16 * HS);
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, Bd_hi, d, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, Bd_hi, d, 0, 0, 0);
+    };
+    auto dense_store = [&](int t, const f32x4 &d) {
+        float *dw = dpart + ((size_t)(t & 1) * 4 * NW + wave) * 64 + lane;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) dw[reg * NW * 64] = d[reg];
+    };
+
+    for (int t = 0; t < T; ++t) {
+        uint32_t b = myseq[dir ? T - 1 - t : t];
+        if (dir) b = b < 4 ? 3 - b : 4;
+        const uint32_t one = 0x3C00u << ((b & 1) * 16);
+        const uint32_t sel = b >> 1;
+        const uint4 xu = make_uint4(sel == 0 ? one : 0u, sel == 1 ? one : 0u, (sel == 2 ? one : 0u) | 0x3C000000u, 0u);
+        const half8 xa = __builtin_bit_cast(half8, xu);
+        const _Float16 *arow = hcur + r * HS + 8 * khalf, *lrow = lcur + r * HS + 8 * khalf;
+
+        uint4 q[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) q[i] = mylo[(size_t)i * 64];
+        // one gate: fragments f0 .. f0+KS-1 of the lo stream
+        auto chain = [&](const half8 (&Bh)[KS + 1], int f0) -> f32x16 {
+            f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[KS], xa, zero16, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                const int f = f0 + k;
+                const half8 hf = *reinterpret_cast<const half8 *>(arow + 16 * k);
+                const half8 lf = *reinterpret_cast<const half8 *>(lrow + 16 * k);
+                const half8 wl = __builtin_bit_cast(half8, q[f % PF]);
+                if (f + PF < NLO) q[f % PF] = mylo[(size_t)(f + PF) * 64];
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[k], hf, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[k], lf, a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hf, a, 0, 0, 0);
+            }
+            return a;
+        };
+        const f32x16 ar = chain(Br, 0);
+        f32x4 dpl = zero4;
+        if (t > 0) dpl = dense_issue(hcur, lcur);
+        if (t > 1) finish_step(t - 2);
+        f32x2 rr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rr[i] = rcp1p_exp2_pair(ar[2 * i], ar[2 * i + 1]);
+        f32x16 ag = chain(Bg, KS);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {                                          // r * (h.U_h + b_rec_h)
+            const f32x2 pr = f32x2{ ag[i], ag[i + 1] } * rr[i / 2];
+            ag[i] = pr.x; ag[i + 1] = pr.y;
+        }
+        ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, ag, 0, 0, 0);            // + x.W_h + b_in_h
+        const f32x16 az = chain(Bz, 2 * KS);
+        if (t > 0) dense_store(t - 1, dpl);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x2 hh = 1.0f - 2.0f * rcp1p_exp2_pair(ag[2 * i], ag[2 * i + 1]);
+            const f32x2 z = rcp1p_exp2_pair(az[2 * i] - p.zfold, az[2 * i + 1] - p.zfold);
+            h[i] = hh + z * (h[i] - hh);                                             // z*h + (1-z)*hh
+        }
+        // publish h_t as an fp16 pair: hi = fp16(h), lo = fp16(h - hi)
+        _Float16 *wrow = hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
+        _Float16 *wlow = lnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const f32x2 h0 = h[2 * qd], h1 = h[2 * qd + 1];
+            const half4 hv = { (_Float16)h0.x, (_Float16)h0.y, (_Float16)h1.x, (_Float16)h1.y };
+            const half4 lv = { (_Float16)(h0.x - (float)hv.x), (_Float16)(h0.y - (float)hv.y), (_Float16)(h1.x - (float)hv.z),
+                               (_Float16)(h1.y - (float)hv.w) };
+            *reinterpret_cast<half4 *>(wrow + 8 * qd) = hv;
+            *reinterpret_cast<half4 *>(wlow + 8 * qd) = lv;
+        }
+        __syncthreads();
+        _Float16 *tmp = hcur; hcur = hnxt; hnxt = tmp;
+        tmp = lcur; lcur = lnxt; lnxt = tmp;
+    }
+    {
+        const f32x4 dpl = dense_issue(hcur, lcur);
+        if (T > 1) finish_step(T - 2);
+        dense_store(T - 1, dpl);
+        __syncthreads();
+        finish_step(T - 1);
+    }
+    if (MODE == 0 && p.ospan > 0) flush_image<NW>(p, ctx);
+}
+
 // ------------------------------------------------------------------------------------------
 // rnn = "LSTM" (deepgrp/model.py:219-223): same decomposition as the GRU kernel -- a workgroup owns 16
 // windows (32 rows), wave w owns units [32w, 32w+32) of all FOUR gates (i|f|c|o), fp32 cell and hidden
@@ -1129,6 +1280,26 @@ static int launch_gru(const gru_params &p, int64_t groups, size_t lds, bool oner
 }
 
 template <int NW>
+static int launch_split(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
+{
+    static bool configured = false;
+    if (!configured) {
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    if (p.mode == 0)
+        hipLaunchKernelGGL((gru_split_kernel<NW, 0>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+    else
+        hipLaunchKernelGGL((gru_split_kernel<NW, 1>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
+// split-operand kernel selected (dgrp_model_set_precision) and applicable to this launch
+static bool use_split(const dgrp_model *m, int mode) { return m->precision == 1 && m->cell == 0 && m->NW <= 4 && mode != 2 && m->d_pack_lo; }
+
+template <int NW>
 static int launch_lstm(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
     static bool configured = false;
@@ -1167,19 +1338,31 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
         p.stamps = d_stamps;
     }
 #endif
+    const bool split = use_split(m, mode);
+    const int lo_tiles = split ? gru_lds_hbuf(m->UP) : 0;           // the lo halves of the hidden tile, behind everything else
     const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
     p.ospan = 0;
     if (mode == 0) {
         // rows spanned by 16 consecutive windows, capped so that two workgroups fit a CU's 160 KiB
         const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
-        const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed) / (m->C * 4);   // NW > 4: one workgroup per CU anyway
+        const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed - lo_tiles) / (m->C * 4);   // NW > 4: one workgroup per CU anyway
         p.ospan = (int)(want < cap ? want : cap);
         if (p.ospan < m->T) p.ospan = 0;
     }
-    const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
+    p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
+    p.lo_tile_off = (int)dgrp_align_up(fixed + (int64_t)p.ospan * m->C * 4, 16);
+    const size_t lds = split ? (size_t)p.lo_tile_off + lo_tiles : (size_t)fixed + (size_t)p.ospan * m->C * 4;
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T, fixed);
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
+    if (split) {
+        switch (m->NW) {
+        case 1: return launch_split<1>(p, groups, lds, stream);
+        case 2: return launch_split<2>(p, groups, lds, stream);
+        case 3: return launch_split<3>(p, groups, lds, stream);
+        default: return launch_split<4>(p, groups, lds, stream);
+        }
+    }
     if (m->cell == 1) {
         switch (m->NW) {
         case 1: return launch_lstm<1>(p, groups, lds, stream);
@@ -1231,14 +1414,26 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     p.Tp = (int)dgrp_align_up(m->T, 16);
     p.stamps = nullptr;
     p.recs = (const gru_rec *)d_recs; p.wg_first = d_wg_first; p.nrec = nrec; p.avgw = 0;
+    const bool split = use_split(m, mode);
+    const int lo_tiles = split ? gru_lds_hbuf(m->UP) : 0;
     const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
     const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
-    const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed) / (m->C * 4);
+    const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed - lo_tiles) / (m->C * 4);
     p.ospan = mode == 0 ? (int)(want < cap ? want : cap) : 0;
     if (p.ospan < m->T) p.ospan = 0;
-    const size_t lds = (size_t)fixed + (size_t)p.ospan * m->C * 4;
+    p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
+    p.lo_tile_off = (int)dgrp_align_up(fixed + (int64_t)p.ospan * m->C * 4, 16);
+    const size_t lds = split ? (size_t)p.lo_tile_off + lo_tiles : (size_t)fixed + (size_t)p.ospan * m->C * 4;
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T, fixed);
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
+    if (split) {
+        switch (m->NW) {
+        case 1: return launch_split<1>(p, total_groups, lds, stream);
+        case 2: return launch_split<2>(p, total_groups, lds, stream);
+        case 3: return launch_split<3>(p, total_groups, lds, stream);
+        default: return launch_split<4>(p, total_groups, lds, stream);
+        }
+    }
     if (m->cell == 1) {
         switch (m->NW) {
         case 1: return launch_lstm<1>(p, total_groups, lds, stream);

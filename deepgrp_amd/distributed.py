@@ -113,6 +113,7 @@ def merged_split(pipe, d_idx: torch.Tensor) -> torch.Tensor:
     if b > a:
         if m.attention:
             raise NotImplementedError("splitting one record over GPUs is implemented for models without attention")
+        m.set_precision(1 if getattr(pipe, "split", False) else 0)
         # absolute row indexing: hand the kernel the address row 0 would have
         base = local.data_ptr() - lo * C_ * 4
         check(L.dgrp_forward_merge(m.handle, d_idx.data_ptr(), n, pipe.step, pipe.batch, a, b - a, base, None, 0, stream_ptr()),

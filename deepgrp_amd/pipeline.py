@@ -112,8 +112,18 @@ class DeviceModel:
 
     @property
     def kernel_flags(self) -> int:
-        """dgrp_model_flags: bit 0 = the one-reciprocal GRU blend was provably safe for these weights."""
+        """dgrp_model_flags: bit 0 = the one-reciprocal GRU blend was provably safe for these weights, bit 1 = the
+        split-operand kernel is selected."""
         return int(lib().dgrp_model_flags(self.handle))
+
+    @property
+    def supports_split(self) -> bool:
+        """The split-operand fused kernel (fp16 hi+lo pairs, fp32-grade pre-activations) covers this model."""
+        return self.rnn == "GRU" and not self.attention and self.units <= 128
+
+    def set_precision(self, level: int) -> None:
+        """dgrp_model_set_precision: 0 = fp16 operands (default), 1 = split operands, for every later call."""
+        check(lib().dgrp_model_set_precision(self.handle, int(level)), "dgrp_model_set_precision")
 
     def close(self):
         if getattr(self, "handle", None):
@@ -146,10 +156,19 @@ class DeviceModel:
                                                    _ptr(work), work.numel(), stream_ptr()), "dgrp_forward_windows_reference")
         return probs
 
-    def check_accuracy(self, d_idx: Optional[torch.Tensor] = None, step: int = 50, windows: int = 256, seed: int = 0) -> dict:
+    def check_accuracy(self, d_idx: Optional[torch.Tensor] = None, step: int = 50, windows: int = 256, seed: int = 0,
+                       level: Optional[int] = None) -> dict:
         """Largest deviation of the fused kernel's class probabilities from the fp32 yardstick on up to `windows`
         windows spread evenly over the class-index tensor `d_idx` (default: a random ACGT sequence).  The bound the
-        path is built to is 1e-3 (BASELINE north star)."""
+        path is built to is 1e-3 (BASELINE north star).  `level` picks the fused kernel for the comparison (0 = fp16
+        operands, 1 = split operands; default: the model's current setting) and is restored afterwards."""
+        if level is not None:
+            before = 1 if self.kernel_flags & 2 else 0
+            self.set_precision(level)
+            try:
+                return self.check_accuracy(d_idx, step, windows, seed)
+            finally:
+                self.set_precision(before)
         dev = require_gpu()
         if d_idx is None:
             rng = np.random.default_rng(seed)
@@ -215,7 +234,8 @@ class ContigPipeline:
     """Runs records through the device pipeline with the reference's CLI parameters."""
 
     def __init__(self, model: DeviceModel, step_size: int = 50, batch_size: int = 256, min_mss_len: int = 50,
-                 xdrop_len: int = 50, use_mss: bool = True, chunk_windows: int = 1 << 20, precise: bool = False):
+                 xdrop_len: int = 50, use_mss: bool = True, chunk_windows: int = 1 << 20, precise: bool = False,
+                 fast: bool = False):
         self.model = model
         self.step = int(step_size)
         self.batch = int(batch_size)
@@ -223,9 +243,16 @@ class ContigPipeline:
         self.xdrop_len = int(xdrop_len)
         self.use_mss = bool(use_mss)
         self.chunk_windows = int(chunk_windows)
-        # precise: the forward pass goes through the plain-fp32 kernels (ref_kernels.hip) instead of the fused fp16-operand
-        # kernel -- ~20x slower, probabilities within ~1e-6 of an fp32 framework (`predict --precise`)
-        self.precise = bool(precise)
+        # Which forward kernel runs ("accuracy"):
+        #   default  the split-operand fused kernel where it exists (GRU without attention, <= 128 units: every base within
+        #            ~1e-6 of fp32), the fp16-operand fused kernel for the other models;
+        #   fast     the fp16-operand fused kernel everywhere (2.8x faster; 1e-3 on all but ill-conditioned windows);
+        #   precise  like default, but models without a split kernel go through the plain-fp32 kernels (30 Mbp/s).
+        if precise and fast:
+            raise ValueError("precise and fast exclude each other")
+        self.precise, self.fast = bool(precise), bool(fast)
+        self.split = not self.fast and bool(getattr(model, "supports_split", False))
+        self.fp32 = self.precise and not self.split
         self.event_log = None        # bench.py: list collecting (start, end, windows) per GRU launch
         if self.step < 1 or self.batch < 1:
             raise ValueError("step_size and batch_size must be >= 1")
@@ -236,7 +263,8 @@ class ContigPipeline:
         n = d_idx.numel()
         out = torch.zeros((n, m.classes), dtype=torch.float32, device=d_idx.device)      # np.zeros, prediction.py:103
         nwin = L.dgrp_window_count(n, m.vecsize, self.step)
-        if self.precise:
+        m.set_precision(1 if self.split else 0)
+        if self.fp32:
             # the reference's own loop (prediction.py:104-110): batches of B windows, batch i lands at row i * b * step
             # (b = size of THAT batch); the forward pass runs for several batches at a time
             B = self.batch
@@ -325,8 +353,9 @@ class ContigPipeline:
     def run_idx(self, d_idx: torch.Tensor, startpos: int, contig: int = 0) -> np.ndarray:
         """Segment records of one record whose class indices are on the device: one dgrp_predict_record call
         (the staged merged -> labels -> segments path is kept for callers that time or inspect the stages)."""
-        if self.event_log is not None or self.precise:
+        if self.event_log is not None or self.fp32:
             return self.segments(self.labels(self.merged(d_idx)), startpos, contig)
+        self.model.set_precision(1 if self.split else 0)
         L = lib()
         n = d_idx.numel()
         if n == 0:
@@ -349,7 +378,7 @@ class ContigPipeline:
 
     def batchable(self) -> bool:
         """dgrp_predict_batch covers every model on the MSS path (the -m softmax is normalised per record)."""
-        return self.use_mss and self.event_log is None and not self.precise
+        return self.use_mss and self.event_log is None and not self.fp32
 
     def run_batch(self, d_base: torch.Tensor, offsets, lengths, startposes, contigs) -> np.ndarray:
         """Segment records of MANY short records whose class indices lie in one device buffer (record r: `lengths[r]`
@@ -358,6 +387,7 @@ class ContigPipeline:
         nrec = len(lengths)
         if nrec == 0:
             return np.zeros(0, SEGMENT_DTYPE)
+        self.model.set_precision(1 if self.split else 0)
         off = np.ascontiguousarray(offsets, np.int64)
         ln = np.ascontiguousarray(lengths, np.int64)
         sp = np.ascontiguousarray(startposes, np.int64)

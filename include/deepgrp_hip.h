@@ -115,6 +115,10 @@ int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int *attention)
  * prove (1 + 2^az)(1 + 2^ag) finite in float32; otherwise (or with DGRP_GRU_SAFE=1 in the environment at
  * construction) the two-reciprocal form.  Negative on a NULL model. */
 int dgrp_model_flags(const dgrp_model *m);
+/* (addition) Precision of the recurrent contraction for every later call on this model: 0 = fp16 MFMA operands (default,
+ * the benchmarked path); 1 = split operands: weights and hidden state as fp16 hi+lo pairs, three MFMA passes, fp32-grade
+ * pre-activations (GRU without attention, <= 128 units; DGRP_EINVAL otherwise).  dgrp_model_flags bit 1 reports it. */
+int dgrp_model_set_precision(dgrp_model *m, int level);
 
 /* ---- A4: model.predict_on_batch (deepgrp/prediction.py:106)
  * Bytes of scratch HBM dgrp_forward_* needs for `nw` windows in one call. */

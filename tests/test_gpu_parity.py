@@ -136,11 +136,20 @@ def test_forward_windows_vs_oracle(dev, orc, u, T, attention, gain, s, nw):
     n = (nw + 2) * s + T
     idx = _seq_idx(rng, n)
     want = orc.nn_forward(idx, w, s, 2, nw, np.float64)
-    got = dm.forward_windows(_t(idx, dev), s, 2, nw).cpu().numpy()
-    err = np.abs(got - want).max()
-    print(f"u={u} T={T} att={attention} gain={gain}: max |dp| = {err:.2e}")
-    assert err < 1e-3
-    np.testing.assert_allclose(got.sum(axis=2), 1.0, atol=1e-5)
+    # both fused kernels: fp16 operands (the fast mode; the default for models without a split kernel) to 1e-3, split
+    # operands (the default where it exists) to fp32 rounding
+    for level, tol in ((0, 1e-3),) + (((1, 1e-5),) if dm.supports_split else ()):
+        dm.set_precision(level)
+        assert bool(dm.kernel_flags & 2) == bool(level)
+        got = dm.forward_windows(_t(idx, dev), s, 2, nw).cpu().numpy()
+        err = np.abs(got - want).max()
+        print(f"u={u} T={T} att={attention} gain={gain} level={level}: max |dp| = {err:.2e}")
+        assert err < tol
+        np.testing.assert_allclose(got.sum(axis=2), 1.0, atol=1e-5)
+    if not dm.supports_split:
+        from deepgrp_amd._lib import DgrpError
+        with pytest.raises(DgrpError, match="split-operand kernel covers"):
+            dm.set_precision(1)
     dm.close()
 
 
@@ -158,6 +167,7 @@ def test_gru_blend_variants_agree(dev, orc, u, T, attention, monkeypatch):
     _, safe = _model(orc, u, T, attention, 1.0)
     monkeypatch.delenv("DGRP_GRU_SAFE")
     assert not (safe.kernel_flags & 1)
+    fast.set_precision(0), safe.set_precision(0)                # this test is about the two fp16-operand kernels
     want = orc.nn_forward(idx, w, s, 0, nw, np.float64)
     a = fast.forward_windows(_t(idx, dev), s, 0, nw).cpu().numpy()
     b = safe.forward_windows(_t(idx, dev), s, 0, nw).cpu().numpy()
@@ -174,6 +184,7 @@ def test_gru_large_weights_take_the_safe_blend(dev, orc):
     u, T, s, nw = 128, 60, 13, 29
     w, dm = _model(orc, u, T, False, 12.0)
     assert not (dm.kernel_flags & 1)
+    dm.set_precision(0)
     idx = _seq_idx(rng, (nw + 2) * s + T)
     got = dm.forward_windows(_t(idx, dev), s, 0, nw).cpu().numpy()
     assert np.isfinite(got).all()

@@ -41,8 +41,10 @@ def test_reference_kernel_vs_oracle(dev, orc, u, T, attention, gain, s, nw, C_):
     got = dm.forward_windows_reference(torch.from_numpy(idx).to(dev), s, 1, nw).cpu().numpy()
     want = orc.nn_forward(idx, w, s, 1, nw, np.float64)
     assert np.abs(got - want).max() < 2e-5                       # fp32 vs float64 through T recurrent steps
-    fast = dm.forward_windows(torch.from_numpy(idx).to(dev), s, 1, nw).cpu().numpy()
-    assert np.abs(fast - got).max() < 1e-3
+    for level in (0, 1) if dm.supports_split else (0,):
+        dm.set_precision(level)
+        fused = dm.forward_windows(torch.from_numpy(idx).to(dev), s, 1, nw).cpu().numpy()
+        assert np.abs(fused - got).max() < (1e-5 if level else 1e-3)
     dm.close()
 
 
@@ -76,7 +78,10 @@ def test_fused_kernel_vs_yardstick_at_bench_shape(dev):
              ("gain2att", synthetic.synthetic_weights(128, 5, attention=True, seed=9, gain=2.0), 1e-3))
     for name, w, bound in cases:
         dm = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=200)
-        r = dm.check_accuracy(d_idx, 50, 2048)
+        if dm.supports_split:
+            rs = dm.check_accuracy(d_idx, 50, 2048, level=1)                # the default kernel of these models: fp32-grade
+            assert rs["max_abs_diff"] < 1e-5 and rs["argmax_flips"] == 0 and rs["within_1e-3"], (name, rs)
+        r = dm.check_accuracy(d_idx, 50, 2048, level=0)                      # the fp16-operand kernel (--fast)
         assert r["windows_checked"] == 2048 and r["positions_checked"] == 2048 * 200
         if bound is not None:
             assert r["max_abs_diff"] < bound and r["within_1e-3"], (name, r)
@@ -128,10 +133,15 @@ def test_cli_verify(tmp_path):
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l.split("\t") for l in r.stdout.strip().splitlines()]
-    assert [l[1] for l in lines] == ["r0 x", "r2 x"] and all(l[0] == str(fa) and l[5] == "ok" for l in lines)
-    assert all(0 < float(l[2]) < 1e-3 and int(l[3]) >= 64 for l in lines)
-    r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "verify", model], cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.startswith("<random>\tACGT\t")
+    assert [l[1] for l in lines] == ["r0 x", "r2 x"] and all(l[0] == str(fa) and l[2] == "fp16" and l[6] == "ok" for l in lines)
+    assert all(0 < float(l[3]) < 1e-3 and int(l[4]) >= 64 for l in lines)
+    # a GRU model without attention: one line per fused kernel, the split one at fp32 rounding
+    r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "verify", os.path.join(GOLDEN, "model_u8_T20.h5")], cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l.split("\t") for l in r.stdout.strip().splitlines()]
+    assert [(l[0], l[1], l[2]) for l in lines] == [("<random>", "ACGT", "split"), ("<random>", "ACGT", "fp16")]
+    assert float(lines[0][3]) < 1e-5 and float(lines[1][3]) < 1e-3
 
 
 # --------------------------------------------------------------------------------- precise mode (predict --precise)
@@ -147,7 +157,7 @@ def test_precise_pipeline_vs_oracle(dev, orc, u, T, attention, use_mss, B):
     body = "".join(rng.choice(list("ACGT"), size=20011))
     seq = "NNNN" + body[:7000] + "N" * 300 + body[7000:] + "NN"
     pipe = ContigPipeline(dm, 50, B, 50, 50, use_mss, precise=True)
-    assert not pipe.batchable()
+    assert pipe.split == (not attention) and pipe.fp32 == attention and pipe.batchable() == (use_mss and not attention)
     st, d_idx = upload_sequence(seq.encode())
     idx = d_idx.cpu().numpy()
     nwin = orc.window_count(idx.size, T, 50)
@@ -159,9 +169,11 @@ def test_precise_pipeline_vs_oracle(dev, orc, u, T, attention, use_mss, B):
     probs = dm.forward_windows_reference(d_idx, 50, 0, nwin).cpu().numpy()
     want = orc.predict_contig(seq, lambda _idx: (lambda a, b: probs[a:a + b]), T, 5, 50, B, 50, 50, use_mss)
     np.testing.assert_array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3), want)
-    # the fast path on a random-weight model (near-tie calls everywhere) differs in a handful of rows at most
-    fast = ContigPipeline(dm, 50, B, 50, 50, use_mss).run(seq, contig=1)
+    # the fp16-operand kernel on a random-weight model (near-tie calls everywhere) differs in a handful of rows at most
+    fast = ContigPipeline(dm, 50, B, 50, 50, use_mss, fast=True).run(seq, contig=1)
     assert abs(len(fast) - len(rows)) <= max(3, len(rows) // 100)
+    with pytest.raises(ValueError, match="exclude"):
+        ContigPipeline(dm, 50, B, 50, 50, use_mss, precise=True, fast=True)
     dm.close()
 
 
@@ -171,14 +183,14 @@ def test_cli_precise(tmp_path, orc):
     fa.write_text("".join(f">c{i}\n{''.join(rng.choice(list('ACGT'), size=n))}\n" for i, n in enumerate((6000, 100, 8000))))
     model = os.path.join(GOLDEN, "model_u60_T342_att.h5")
     outs = []
-    for extra in ([], ["--precise"]):
-        out = tmp_path / f"o{len(extra)}.tsv"
+    for extra in ([], ["--precise"], ["--fast"]):
+        out = tmp_path / f"o{'_'.join(extra)}.tsv"
         r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "predict", model, str(fa), "--output", str(out)] + extra,
                            cwd=ROOT, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(out.read_text())
     # the golden model's calls do not hinge on the fourth decimal: both modes print the same table
-    assert outs[0] == outs[1] and outs[0].count("\n") > 0
-    r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "predict", model, str(fa), "--precise", "--split_contigs"],
+    assert outs[0] == outs[1] == outs[2] and outs[0].count("\n") > 0
+    r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "predict", model, str(fa), "--precise", "--fast"],
                        cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "--precise" in r.stderr
+    assert r.returncode != 0 and "exclude" in r.stderr

@@ -13,11 +13,14 @@ w = synthetic.trained_weights() if kind == "trained" else synthetic.synthetic_we
 m = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=200)
 st, d_idx = upload_sequence(synthetic.synthetic_chromosome(int(mbp * 1e6)))
 fast, precise = ContigPipeline(m), ContigPipeline(m, precise=True)
+if len(sys.argv) > 3 and sys.argv[3] == "fp32":
+    precise.split = False                      # force the plain-fp32 kernels instead of the split-operand fused kernel
+print("precise mode:", "split-operand fused kernel" if precise.split else "plain-fp32 kernels", flush=True)
 def T():
     torch.cuda.synchronize(); return time.perf_counter()
 fast.merged(d_idx)
-t0 = T(); mf = fast.merged(d_idx); t1 = T(); mp = precise.merged(d_idx); t2 = T()
-print(f"{mbp:g} Mbp {kind}: fast forward+merge {1e3*(t1-t0):.1f} ms ({mbp/(t1-t0):.0f} Mbp/s), precise {1e3*(t2-t1):.1f} ms ({mbp/(t2-t1):.1f} Mbp/s)", flush=True)
+t0 = T(); mf = fast.merged(d_idx); t1 = T(); precise.merged(d_idx); t1b = T(); mp = precise.merged(d_idx); t2 = T(); t1 = t1 - (t1b - t1) * 0; t0p = t1b
+print(f"{mbp:g} Mbp {kind}: fast forward+merge {1e3*(t1-t0):.1f} ms ({mbp/(t1-t0):.0f} Mbp/s), precise {1e3*(t2-t0p):.1f} ms ({mbp/(t2-t0p):.1f} Mbp/s)", flush=True)
 d = (mf - mp).abs().amax(dim=1)
 q = torch.quantile(d[:: max(1, d.numel() // 4_000_000)].double(), torch.tensor([0.5, 0.9, 0.99, 0.999, 0.9999], dtype=torch.float64, device=d.device)).cpu().numpy()
 print("per-base max|dp| of the merged probabilities: median %.2e  q90 %.2e  q99 %.2e  q99.9 %.2e  q99.99 %.2e  worst %.2e;  bases above 1e-3: %d of %d (%.4f %%)"
