@@ -244,14 +244,14 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
                           attention ? scale : nullptr));
     if (m->NW <= 4) {
         // lo halves of the recurrent fragments for the split-operand kernel: what fp16 rounding dropped from the
-        // scaled weight, in the kernel's consumption order r, g, z
+        // scaled weight, in the kernel's consumption order: k-step major, gates r, g, z
         std::vector<uint16_t> lo((size_t)m->NW * 3 * KS * 64 * 8, 0);
         static const int order[3] = { 1, 2, 0 };
         for (int w = 0; w < m->NW; ++w)
-            for (int gi = 0; gi < 3; ++gi) {
-                const int g = order[gi];
-                const float gs = g < 2 ? -1.4426950408889634f : 2.8853900817779268f;
-                for (int ks = 0; ks < KS; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int gi = 0; gi < 3; ++gi) {
+                    const int g = order[gi];
+                    const float gs = g < 2 ? -1.4426950408889634f : 2.8853900817779268f;
                     for (int l = 0; l < 64; ++l) {
                         const int unit = 32 * w + (l & 31);
                         for (int j = 0; j < 8; ++j) {
@@ -261,7 +261,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
                                 const float x = gs * rec[(size_t)k * u3 + g * u + unit];
                                 v = f2h(x - h2f(f2h(x)));
                             }
-                            lo[((((size_t)w * 3 + gi) * KS + ks) * 64 + l) * 8 + j] = v;
+                            lo[((((size_t)w * KS + ks) * 3 + gi) * 64 + l) * 8 + j] = v;
                         }
                     }
             }

@@ -13,7 +13,7 @@ struct dgrp_model {
     int nfrag;   // fragments per wave: 3*(KS+1) gate fragments + x->h~ + dense hi + dense lo
     int precision;    // 0: fused fp16-operand kernel; 1: split-operand kernel where it applies (dgrp_model_set_precision)
     uint4 *d_pack;    // [NW][nfrag][64] 8 x fp16 per lane
-    uint4 *d_pack_lo; // GRU, NW <= 4: [NW][3 KS][64] lo halves of the recurrent fragments in the order r, g, z, or NULL
+    uint4 *d_pack_lo; // GRU, NW <= 4: [NW][KS][3][64] lo halves of the recurrent fragments (k-step major, gates r, g, z), or NULL
     float *d_ffb;     // [16] dense bias, zero padded
     float *d_scale;   // [UP] attention scale (zero padded) or NULL
     float *d_wtop;    // [UP][16] rows of the dense kernel that multiply the context vector, or NULL

@@ -68,7 +68,7 @@ struct gru_params {
     const int64_t *wg_first;
     int64_t nrec;
     int64_t avgw;         // modes 1, 2: row of window w0 in the output / spill buffers (batched records: the record's first)
-    // split-operand kernel only: the lo halves of the recurrent fragments ([NW][3 KS][64] in the order r, g, z), the byte
+    // split-operand kernel only: the lo halves of the recurrent fragments ([NW][KS][3][64]: k-step major, gates r, g, z), the byte
     // offset of the lo hidden tiles in the dynamic LDS, and 1.0 if the packed z bias carries the one-reciprocal "+1"
     const uint4 *pack_lo;
     int lo_tile_off;
@@ -622,15 +622,18 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 // U = U_hi + U_lo (packed once), h_{t-1} = h_hi + h_lo (two LDS tiles), and  U.h ~ U_hi.h_hi + U_hi.h_lo + U_lo.h_hi
 // (the dropped U_lo.h_lo term is below 2^-22 of the product).  Three MFMAs per k-step instead of one: the matrix pipe,
 // half idle in the fast kernel, becomes the bound.  U_hi stays resident in VGPRs; the U_lo fragments stream from L2
-// every step through a 4-deep register ring in consumption order (r, g, z); the hidden tile's fragments are re-read
-// from LDS at every use.  Dense takes the lo tile too.  Written for correctness first: no staging of the softmax into
+// every step through a small register ring in consumption order (k-step major, gates r, g, z); the hidden tile's two
+// fragments are read from LDS once per k-step.  Dense takes the lo tile too.  Written for correctness first: no staging of the softmax into
 // MFMA gaps, two reciprocals.  GRU without attention, up to 128 units.
 template <int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params pin)
 {
     gru_params p = pin;
     const int64_t bid = wg_record<MODE>(pin, p);
-    constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8, NLO = 3 * KS, PF = 4;
+#ifndef DGRP_SPLIT_PF
+#define DGRP_SPLIT_PF 6
+#endif
+    constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8, NLO = 3 * KS, PF = DGRP_SPLIT_PF < NLO ? DGRP_SPLIT_PF : NLO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -696,45 +699,51 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
         const half8 xa = __builtin_bit_cast(half8, xu);
         const _Float16 *arow = hcur + r * HS + 8 * khalf, *lrow = lcur + r * HS + 8 * khalf;
 
+        // All three contractions advance together, k-step by k-step: the two fragments of the hidden tile are read once
+        // per k-step and serve nine MFMAs on three independent accumulators (no dependent back-to-back issue), one
+        // lo weight fragment per gate arrives from the ring.  The lo stream is packed in this order: f = 3 k + gate,
+        // gates r, g, z.
         uint4 q[PF];
 #pragma unroll
         for (int i = 0; i < PF; ++i) q[i] = mylo[(size_t)i * 64];
-        // one gate: fragments f0 .. f0+KS-1 of the lo stream
-        auto chain = [&](const half8 (&Bh)[KS + 1], int f0) -> f32x16 {
-            f32x16 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[KS], xa, zero16, 0, 0, 0);
+        f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
+        f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[KS], xa, zero16, 0, 0, 0);
+        f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[KS], xa, zero16, 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < KS; ++k) {
-                const int f = f0 + k;
-                const half8 hf = *reinterpret_cast<const half8 *>(arow + 16 * k);
-                const half8 lf = *reinterpret_cast<const half8 *>(lrow + 16 * k);
-                const half8 wl = __builtin_bit_cast(half8, q[f % PF]);
+        for (int k = 0; k < KS; ++k) {
+            const half8 hf = *reinterpret_cast<const half8 *>(arow + 16 * k);
+            const half8 lf = *reinterpret_cast<const half8 *>(lrow + 16 * k);
+            half8 wl[3];
+#pragma unroll
+            for (int gi = 0; gi < 3; ++gi) {
+                const int f = 3 * k + gi;
+                wl[gi] = __builtin_bit_cast(half8, q[f % PF]);
                 if (f + PF < NLO) q[f % PF] = mylo[(size_t)(f + PF) * 64];
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[k], hf, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[k], lf, a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, hf, a, 0, 0, 0);
             }
-            return a;
-        };
-        const f32x16 ar = chain(Br, 0);
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], hf, ar, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], hf, ag, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[k], hf, az, 0, 0, 0);
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], lf, ar, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], lf, ag, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[k], lf, az, 0, 0, 0);
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0], hf, ar, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[1], hf, ag, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[2], hf, az, 0, 0, 0);
+        }
         f32x4 dpl = zero4;
         if (t > 0) dpl = dense_issue(hcur, lcur);
         if (t > 1) finish_step(t - 2);
-        f32x2 rr[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rr[i] = rcp1p_exp2_pair(ar[2 * i], ar[2 * i + 1]);
-        f32x16 ag = chain(Bg, KS);
 #pragma unroll
         for (int i = 0; i < 16; i += 2) {                                          // r * (h.U_h + b_rec_h)
-            const f32x2 pr = f32x2{ ag[i], ag[i + 1] } * rr[i / 2];
+            const f32x2 pr = f32x2{ ag[i], ag[i + 1] } * rcp1p_exp2_pair(ar[i], ar[i + 1]);
             ag[i] = pr.x; ag[i + 1] = pr.y;
         }
         ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, ag, 0, 0, 0);            // + x.W_h + b_in_h
-        const f32x16 az = chain(Bz, 2 * KS);
         if (t > 0) dense_store(t - 1, dpl);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const f32x2 hh = 1.0f - 2.0f * rcp1p_exp2_pair(ag[2 * i], ag[2 * i + 1]);
             const f32x2 z = rcp1p_exp2_pair(az[2 * i] - p.zfold, az[2 * i + 1] - p.zfold);
+            const f32x2 hh = 1.0f - 2.0f * rcp1p_exp2_pair(ag[2 * i], ag[2 * i + 1]);
             h[i] = hh + z * (h[i] - hh);                                             // z*h + (1-z)*hh
         }
         // publish h_t as an fp16 pair: hi = fp16(h), lo = fp16(h - hi)

@@ -12,7 +12,7 @@ dev = require_gpu()
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 it = 0
-worst = 0.0
+worst = worst_split = 0.0
 while time.time() < t_end:
     it += 1
     u = int(rng.choice([4, 8, 16, 31, 32, 33, 60, 64, 65, 96, 100, 128, 129, 160, 200, 256]))
@@ -31,7 +31,9 @@ while time.time() < t_end:
     else:
         w = orc.Weights.random(u, 5, T, att, seed=int(rng.integers(0, 1 << 30)), gain=gain)
         m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
-    pipe = ContigPipeline(m, s, B, ml, xd, use_mss=use_mss)
+    fast = bool(rng.integers(0, 2))                    # the fp16-operand kernel, or the default (split operands where they exist)
+    pipe = ContigPipeline(m, s, B, ml, xd, use_mss=use_mss, fast=fast)
+    m.set_precision(1 if pipe.split else 0)
     lens = [int(x) for x in rng.choice([1, 2, T, T + 1, T + s, 64, 65, 500, 3000, 9000], size=6)]
     if rng.integers(0, 8) == 0:
         lens[int(rng.integers(0, 6))] = int(rng.integers(50_000, 260_000))
@@ -40,7 +42,7 @@ while time.time() < t_end:
         pos += int(rng.integers(0, 9)); offs.append(pos); pos += n
     base = rng.choice(5, size=pos + 3, p=[.24, .25, .25, .24, .02]).astype(np.uint8)
     d_base = torch.from_numpy(base).to(dev)
-    tag = f"it {it}: u={u} T={T} s={s} B={B} att={att} lstm={lstm} gain={gain} mss=({ml},{xd}) use_mss={use_mss} lens={lens}"
+    tag = f"it {it}: u={u} T={T} s={s} B={B} att={att} lstm={lstm} gain={gain} split={pipe.split} mss=({ml},{xd}) use_mss={use_mss} lens={lens}"
     try:
         singles = []
         for i, (o, n) in enumerate(zip(offs, lens)):
@@ -54,8 +56,12 @@ while time.time() < t_end:
                 got = m.forward_windows(d_idx, s, 0, nw).cpu().numpy()
                 want = (orc.lstm_forward if lstm else orc.nn_forward)(idx, w, s, 0, nw, np.float64)
                 err = float(np.abs(got - want).max())
-                worst = max(worst, err)
-                assert err < 1e-3, f"forward error {err}"
+                if pipe.split:
+                    worst_split = max(worst_split, err)
+                    assert err < 1e-5, f"forward error {err} (split operands)"
+                else:
+                    worst = max(worst, err)
+                    assert err < 1e-3, f"forward error {err}"
             probs = m.forward_windows(d_idx, s, 0, nwin).cpu().numpy() if nwin else np.zeros((0, T, 5), np.float32)
             merged = orc.predict_merged(idx, lambda a, b: probs[a:a + b], T, 5, s, B)
             lab = orc.labels_from_merged(merged, ml, xd, use_mss)
@@ -69,5 +75,5 @@ while time.time() < t_end:
         sys.exit(1)
     m.close()
     if it % 20 == 0:
-        print(f"{it} configurations ok, worst forward error {worst:.2e}", flush=True)
-print(f"done: {it} configurations ok, worst forward error {worst:.2e}")
+        print(f"{it} configurations ok, worst forward error {worst:.2e} (fp16 operands) {worst_split:.2e} (split operands)", flush=True)
+print(f"done: {it} configurations ok, worst forward error {worst:.2e} (fp16 operands) {worst_split:.2e} (split operands)")
