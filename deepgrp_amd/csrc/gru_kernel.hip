@@ -1288,6 +1288,203 @@ static int launch_gru(const gru_params &p, int64_t groups, size_t lds, bool oner
     }
 }
 
+// ---- split operands, two row tiles per wave, everything resident (128-unit models, single-record launches) ----------
+// One wave per SIMD with the 512-register budget: U_hi AND U_lo of the wave's 32 units live in registers, so nothing
+// streams from L2, and the wave carries TWO row tiles (32 windows per workgroup).  The step is software-pipelined across
+// the tiles: while the matrix pipe works through one tile's 72 + 4 MFMAs the wave issues the other tile's gate math
+// between them (a wave issues in order; what sits between two MFMAs runs in their shadow).  LDS: each tile has the full
+// carve of a 16-window workgroup (`half_bytes` apart), so the shared helpers apply unchanged with workgroup index
+// 2 * blockIdx.x + tile.
+template <int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gru_split2_kernel(const gru_params p, int half_bytes)
+{
+    constexpr int NW = 4, UP = 128, KS = 8, HS = UP + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int T = p.T, C = p.C;
+    const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
+    const uint4 *mylo = p.pack_lo + (size_t)wave * 3 * KS * 64 + lane;
+    half8 Bz[KS + 1], Br[KS + 1], Bg[KS + 1], Lr[KS], Lg[KS], Lz[KS], Bxh, Bd_hi, Bd_lo;
+#pragma unroll
+    for (int k = 0; k <= KS; ++k) {
+        Bz[k] = __builtin_bit_cast(half8, mypack[(size_t)(k) * 64]);
+        Br[k] = __builtin_bit_cast(half8, mypack[(size_t)(KS + 1 + k) * 64]);
+        Bg[k] = __builtin_bit_cast(half8, mypack[(size_t)(2 * (KS + 1) + k) * 64]);
+    }
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        Lr[k] = __builtin_bit_cast(half8, mylo[(size_t)(3 * k) * 64]);
+        Lg[k] = __builtin_bit_cast(half8, mylo[(size_t)(3 * k + 1) * 64]);
+        Lz[k] = __builtin_bit_cast(half8, mylo[(size_t)(3 * k + 2) * 64]);
+    }
+    Bxh = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1)) * 64]);
+    Bd_hi = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 1) * 64]);
+    Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 2) * 64]);
+
+    struct tile_state {
+        wg_ctx ctx;
+        _Float16 *hcur, *hnxt, *lcur, *lnxt;
+        const uint8_t *myseq;
+        f32x2 h[8];
+        f32x16 ar, ag, az, ax;            // pre-activations of the step in flight (ax: the candidate's input projection)
+        f32x4 dpl;
+    };
+    tile_state S0, S1;                      // two named objects, never indexed: they must stay in registers
+    const int r = lane & 31, wi_a = r & 15, dir = r >> 4, khalf = lane >> 5;
+    auto setup = [&](tile_state &X, int x) {
+        unsigned char *base = smem + (size_t)x * half_bytes;
+        _Float16 *lbuf = reinterpret_cast<_Float16 *>(base + p.lo_tile_off);
+        for (int i = tid; i < 32 * HS; i += 256) lbuf[i] = (_Float16)0.0f;
+        X.ctx = wg_setup<NW, MODE>(p, base, 2 * (int64_t)blockIdx.x + x);             // ends with a barrier
+        X.hcur = X.ctx.hbuf; X.hnxt = X.ctx.hbuf + 32 * HS;
+        X.lcur = lbuf; X.lnxt = lbuf + 32 * HS;
+        X.myseq = X.ctx.seqs + wi_a * p.Tp;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) X.h[i] = f32x2{ 0.0f, 0.0f };
+    };
+    setup(S0, 0);
+    setup(S1, 1);
+    const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const f32x4 zero4 = { 0, 0, 0, 0 };
+    const int cls = lane & 15;
+    const float fbias = cls < C ? p.ffb[cls] : 0.0f;
+    const int doff = (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
+
+    auto finish_step = [&](const wg_ctx &ctx, int t) {
+        for (int reg = wave; reg < 4; reg += NW) {
+            const int wi = 4 * (lane >> 4) + reg;
+            finish_register<NW, MODE>(p, ctx, t, reg, fbias, ctx.rowoff[wi], ctx.row0s[wi]);
+        }
+    };
+    auto dense_issue = [&](const _Float16 *hb, const _Float16 *lb) -> f32x4 {
+        const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff), a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
+        const half8 l0 = *reinterpret_cast<const half8 *>(lb + doff), l1 = *reinterpret_cast<const half8 *>(lb + doff + 16 * HS);
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, Bd_hi, d, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, Bd_hi, d, 0, 0, 0);
+    };
+    auto dense_store = [&](const wg_ctx &ctx, int t, const f32x4 &d) {
+        float *dw = ctx.dpart + ((size_t)(t & 1) * 4 * NW + wave) * 64 + lane;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) dw[reg * NW * 64] = d[reg];
+    };
+    // gate math of elements 2i, 2i+1 of a tile whose pre-activations are complete
+    auto gate_piece = [&](tile_state &X, int i) {
+        const f32x2 rr = rcp1p_exp2_pair(X.ar[2 * i], X.ar[2 * i + 1]);
+        const f32x2 g = f32x2{ X.ax[2 * i], X.ax[2 * i + 1] } + rr * f32x2{ X.ag[2 * i], X.ag[2 * i + 1] };
+        const f32x2 hh = 1.0f - 2.0f * rcp1p_exp2_pair(g.x, g.y);
+        const f32x2 z = rcp1p_exp2_pair(X.az[2 * i] - p.zfold, X.az[2 * i + 1] - p.zfold);
+        X.h[i] = hh + z * (X.h[i] - hh);
+    };
+    auto publish = [&](tile_state &X) {
+        _Float16 *wrow = X.hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
+        _Float16 *wlow = X.lnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const f32x2 h0 = X.h[2 * qd], h1 = X.h[2 * qd + 1];
+            const half4 hv = { (_Float16)h0.x, (_Float16)h0.y, (_Float16)h1.x, (_Float16)h1.y };
+            const half4 lv = { (_Float16)(h0.x - (float)hv.x), (_Float16)(h0.y - (float)hv.y), (_Float16)(h1.x - (float)hv.z),
+                               (_Float16)(h1.y - (float)hv.w) };
+            *reinterpret_cast<half4 *>(wrow + 8 * qd) = hv;
+            *reinterpret_cast<half4 *>(wlow + 8 * qd) = lv;
+        }
+        _Float16 *tmp = X.hcur; X.hcur = X.hnxt; X.hnxt = tmp;
+        tmp = X.lcur; X.lcur = X.lnxt; X.lnxt = tmp;
+    };
+    // the 76 MFMAs of tile X's step t; between the k-steps: the gate math of tile Y's step in flight (if any)
+    auto contract = [&](tile_state &X, int t, tile_state &Y, bool with_y) {
+        uint32_t b = X.myseq[dir ? T - 1 - t : t];
+        if (dir) b = b < 4 ? 3 - b : 4;
+        const uint32_t one = 0x3C00u << ((b & 1) * 16);
+        const uint32_t sel = b >> 1;
+        const uint4 xu = make_uint4(sel == 0 ? one : 0u, sel == 1 ? one : 0u, (sel == 2 ? one : 0u) | 0x3C000000u, 0u);
+        const half8 xa = __builtin_bit_cast(half8, xu);
+        const _Float16 *arow = X.hcur + r * HS + 8 * khalf, *lrow = X.lcur + r * HS + 8 * khalf;
+        X.ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
+        X.ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[KS], xa, zero16, 0, 0, 0);
+        X.az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[KS], xa, zero16, 0, 0, 0);
+        X.ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, zero16, 0, 0, 0);
+        // the fragments of k-step k+1 are requested before the MFMAs of k-step k: their LDS latency hides behind nine MFMAs
+        half8 hf = *reinterpret_cast<const half8 *>(arow), lf = *reinterpret_cast<const half8 *>(lrow);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            half8 hfn = hf, lfn = lf;
+            if (k + 1 < KS) {
+                hfn = *reinterpret_cast<const half8 *>(arow + 16 * (k + 1));
+                lfn = *reinterpret_cast<const half8 *>(lrow + 16 * (k + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            X.ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], hf, X.ar, 0, 0, 0);
+            X.ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], hf, X.ag, 0, 0, 0);
+            X.az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[k], hf, X.az, 0, 0, 0);
+            X.ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], lf, X.ar, 0, 0, 0);
+            X.ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], lf, X.ag, 0, 0, 0);
+            X.az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[k], lf, X.az, 0, 0, 0);
+            X.ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Lr[k], hf, X.ar, 0, 0, 0);
+            X.ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Lg[k], hf, X.ag, 0, 0, 0);
+            X.az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Lz[k], hf, X.az, 0, 0, 0);
+            if (with_y) {
+                __builtin_amdgcn_sched_barrier(0);
+                gate_piece(Y, k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            hf = hfn; lf = lfn;
+        }
+        X.dpl = zero4;
+        if (t > 0) X.dpl = dense_issue(X.hcur, X.lcur);           // Dense(t-1) from the tile that is in LDS anyway
+    };
+
+    // prologue: tile 0, step 0
+    contract(S0, 0, S1, false);
+    for (int t = 0; t < T; ++t) {
+        // tile 1's step t  ||  tile 0's gate math of step t
+        contract(S1, t, S0, true);
+        if (t > 0) dense_store(S0.ctx, t - 1, S0.dpl);
+        publish(S0);
+        if (t > 1) finish_step(S0.ctx, t - 2);
+        __syncthreads();                                          // tile 0: h_t and the Dense(t-1) partials are in LDS
+        // tile 0's step t+1  ||  tile 1's gate math of step t
+        if (t + 1 < T) {
+            contract(S0, t + 1, S1, true);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gate_piece(S1, i);
+        }
+        if (t > 0) dense_store(S1.ctx, t - 1, S1.dpl);
+        publish(S1);
+        if (t > 1) finish_step(S1.ctx, t - 2);
+        __syncthreads();
+    }
+    auto drain = [&](tile_state &X) {
+        const f32x4 dpl = dense_issue(X.hcur, X.lcur);
+        if (T > 1) finish_step(X.ctx, T - 2);
+        dense_store(X.ctx, T - 1, dpl);
+        __syncthreads();
+        finish_step(X.ctx, T - 1);
+        if (MODE == 0 && p.ospan > 0) flush_image<NW>(p, X.ctx);
+    };
+    drain(S0);
+    drain(S1);
+}
+
+template <int MODE>
+static int launch_split2(const gru_params &p, int64_t groups, int half_bytes, hipStream_t stream)
+{
+    static bool configured = false;
+    if (!configured) {
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split2_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gru_split2_kernel<MODE>), dim3((unsigned)((groups + 1) / 2)), dim3(256), (size_t)2 * half_bytes, stream, p, half_bytes);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
+}
+
 template <int NW>
 static int launch_split(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
@@ -1365,6 +1562,11 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
     if (split) {
+        // 128-unit class: two row tiles per wave, all fragments resident (no L2 stream) when two carves fit the CU's LDS
+        const int half_bytes = (int)dgrp_align_up((int64_t)lds, 256);
+        static const bool one_tile = getenv("DGRP_SPLIT_ONE_TILE") != nullptr;
+        if (m->NW == 4 && 2 * half_bytes <= 160 * 1024 && groups >= 2 && !one_tile)
+            return mode == 0 ? launch_split2<0>(p, groups, half_bytes, stream) : launch_split2<1>(p, groups, half_bytes, stream);
         switch (m->NW) {
         case 1: return launch_split<1>(p, groups, lds, stream);
         case 2: return launch_split<2>(p, groups, lds, stream);

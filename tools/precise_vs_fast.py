@@ -12,7 +12,7 @@ kind = sys.argv[2] if len(sys.argv) > 2 else "trained"
 w = synthetic.trained_weights() if kind == "trained" else synthetic.synthetic_weights(128, 5, False, 7, 3.0)
 m = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=200)
 st, d_idx = upload_sequence(synthetic.synthetic_chromosome(int(mbp * 1e6)))
-fast, precise = ContigPipeline(m), ContigPipeline(m, precise=True)
+fast, precise = ContigPipeline(m, fast=True), ContigPipeline(m, precise=True)
 if len(sys.argv) > 3 and sys.argv[3] == "fp32":
     precise.split = False                      # force the plain-fp32 kernels instead of the split-operand fused kernel
 print("precise mode:", "split-operand fused kernel" if precise.split else "plain-fp32 kernels", flush=True)

@@ -12,13 +12,14 @@ m = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w
 ow = orc.Weights(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, 200)
 st, d_idx = upload_sequence(synthetic.synthetic_chromosome(int(mbp * 1e6)))
 idx = d_idx.cpu().numpy()
-mf = ContigPipeline(m).merged(d_idx); mp = ContigPipeline(m, precise=True).merged(d_idx)
+mf = ContigPipeline(m, fast=True).merged(d_idx); mp = ContigPipeline(m, precise=True).merged(d_idx)
 d = (mf - mp).abs().amax(dim=1)
 top = torch.topk(d, 8).indices.cpu().numpy()
 for pos in sorted(top):
     wlo = max(0, (pos - 199 + 49) // 50); whi = min(pos // 50, orc.window_count(idx.size, 200, 50) - 1)
     nw = whi - wlo + 1
-    f = m.forward_windows(d_idx, 50, wlo, nw).cpu().numpy()
+    m.set_precision(0)
+    f = m.forward_windows(d_idx, 50, wlo, nw).cpu().numpy()                 # the fp16-operand kernel
     p = m.forward_windows_reference(d_idx, 50, wlo, nw).cpu().numpy()
     o = orc.nn_forward(idx, ow, 50, wlo, nw, np.float64)
     print("base %d dp %.3e  context %s" % (pos, float(d[pos]), "".join("ACGTN"[c] for c in idx[max(0, pos - 12):pos + 12])))
