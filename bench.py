@@ -14,7 +14,7 @@ kernel, MFMA-bound, timed live with HIP events on its stream) and `cpu_baseline`
 restatement of the same path, oracle/, timed on this host on a bounded sample).
 
 The timed path is the package's default for this model: the split-operand GRU kernel, whose class probabilities agree
-with an fp32 evaluation to ~1e-6 on every base (`accuracy`).  `--fast` times the fp16-operand kernel instead (2.8x
+with an fp32 evaluation to ~1e-6 on every base (`accuracy`).  `--fast` times the fp16-operand kernel instead (2.5x
 faster; within 1e-3 of fp32 on 99.98 % of the bases of this workload, not on all); without the flag that mode is
 measured after the timed region and reported as `fast_mode`, for information.
 """
@@ -166,7 +166,8 @@ def main():
     # HBM traffic of that kernel from the PMC passes of profiles/ (separate rocprofv3 --pmc runs of this
     # command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this launch size
     fused_name = "gru_fused_kernel<4, 0, %s>" % ("true" if model.kernel_flags & 1 else "false")
-    kernel_name = fused_name if not pipe.split else "gru_split_kernel<4, 0>"
+    split_name = "gru_split2_kernel<0>"          # 128-unit class, single-record launch: two row tiles per wave (gru_kernel.hip)
+    kernel_name = fused_name if not pipe.split else split_name
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_gru_traffic.json")
     if os.path.exists(tpath) and args.weights == "trained":
@@ -205,7 +206,7 @@ def main():
             out["accuracy"] = dict(yardstick="plain-fp32 HIP kernels (dgrp_forward_windows_reference), themselves within 2e-5 of the float64 CPU statement",
                                    kernel=kernel_name, **acc_obj(model.check_accuracy(d_idx, STEP, args.accuracy_windows, level=1 if pipe.split else 0)))
         if other is not None:
-            other["kernel"] = fused_name if pipe.split else "gru_split_kernel<4, 0>"
+            other["kernel"] = fused_name if pipe.split else split_name
             if args.accuracy_windows > 0:
                 other["accuracy"] = acc_obj(model.check_accuracy(d_idx, STEP, args.accuracy_windows, level=0 if pipe.split else 1))
             out["fast_mode" if pipe.split else "default_mode"] = other

@@ -104,7 +104,7 @@ class CommandLineParser:
         verify.add_argument("FASTA", nargs="*", type=str, help="Fasta input files; none = a random ACGT sequence")
         verify.add_argument("--windows", type=int, default=256, help="windows to compare per record (spread evenly)")
         predict.add_argument("--fast", action="store_true",
-                             help="(addition) fp16-operand fused kernel for every model: 2.8x the default's speed on GRU models "
+                             help="(addition) fp16-operand fused kernel for every model: 2.5x the default's speed on GRU models "
                                   "without attention, class probabilities within 1e-3 of fp32 except on ill-conditioned windows "
                                   "(measure with `verify`)")
         predict.add_argument("--precise", action="store_true",

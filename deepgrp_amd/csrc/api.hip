@@ -269,7 +269,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
         CREATE_HIP(hipMemcpy(m->d_pack_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
         // Default for the models it covers: the split-operand kernel, the one that keeps every base within the 1e-3 of
         // the north star whatever the model's conditioning.  dgrp_model_set_precision(m, 0) or
-        // DGRP_GRU_PRECISION=0 selects the 2.8x faster fp16-operand kernel.
+        // DGRP_GRU_PRECISION=0 selects the 2.5x faster fp16-operand kernel.
         const char *pe = getenv("DGRP_GRU_PRECISION");
         m->precision = (!attention && !(pe && pe[0] == '0')) ? 1 : 0;
     }

@@ -246,7 +246,7 @@ class ContigPipeline:
         # Which forward kernel runs ("accuracy"):
         #   default  the split-operand fused kernel where it exists (GRU without attention, <= 128 units: every base within
         #            ~1e-6 of fp32), the fp16-operand fused kernel for the other models;
-        #   fast     the fp16-operand fused kernel everywhere (2.8x faster; 1e-3 on all but ill-conditioned windows);
+        #   fast     the fp16-operand fused kernel everywhere (2.5x faster; 1e-3 on all but ill-conditioned windows);
         #   precise  like default, but models without a split kernel go through the plain-fp32 kernels (30 Mbp/s).
         if precise and fast:
             raise ValueError("precise and fast exclude each other")

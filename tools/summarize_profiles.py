@@ -25,8 +25,9 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             meta[r["Kernel_Name"]] = (r["VGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"])
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         rows.append((counter, k, len(v), round(sum(v) / len(v), 3)) + meta[k])
-        for tagname in ("gru_fused_kernel", "gru_split_kernel"):
-            if tagname + "<4, 0" in k and len(v) >= 1:        # MODE 0 = forward + merge (MODE 1 launches belong to the accuracy check)
+        for tagname, mode0 in (("gru_fused_kernel", "gru_fused_kernel<4, 0"), ("gru_split_kernel", "gru_split_kernel<4, 0"),
+                               ("gru_split2_kernel", "gru_split2_kernel<0>")):
+            if mode0 in k and len(v) >= 1:        # MODE 0 = forward + merge (MODE 1 launches belong to the accuracy check)
                 # the forward of the whole chromosome is the one launch with ~1 M windows; the accuracy check of
                 # bench.py adds short launches of the same kernels, so take the LARGEST dispatch of each kernel
                 agg.setdefault(tagname, {})[counter] = max(v)
