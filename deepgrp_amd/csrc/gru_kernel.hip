@@ -617,6 +617,19 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 #endif
 }
 
+// Gate math of two adjacent units of the split-operand kernels, written once with explicit fused multiply-adds so that
+// the one-tile and the two-tile kernel (batched records vs. single records of the 128-unit class) round identically:
+// a record must not change its calls with the way it was batched.
+__device__ __forceinline__ f32x2 split_gate(f32x2 ar, f32x2 ag, f32x2 az, f32x2 ax, f32x2 h, float zfold)
+{
+    const f32x2 rr = rcp1p_exp2_pair(ar.x, ar.y);
+    const f32x2 g = __builtin_elementwise_fma(rr, ag, ax);                      // x.W_h + b_in_h + r * (h.U_h + b_rec_h)
+    const f32x2 q = rcp1p_exp2_pair(g.x, g.y);
+    const f32x2 hh = __builtin_elementwise_fma(f32x2{ -2.0f, -2.0f }, q, f32x2{ 1.0f, 1.0f });   // tanh
+    const f32x2 z = rcp1p_exp2_pair(az.x - zfold, az.y - zfold);
+    return __builtin_elementwise_fma(z, h - hh, hh);                              // z*h + (1-z)*hh
+}
+
 // ---- split-operand variant (dgrp_model_set_precision(m, 1)) -------------------------------------------------------
 // Same decomposition, but both MFMA operands of the recurrent contraction carry fp32-grade precision as fp16 pairs:
 // U = U_hi + U_lo (packed once), h_{t-1} = h_hi + h_lo (two LDS tiles), and  U.h ~ U_hi.h_hi + U_hi.h_lo + U_lo.h_hi
@@ -709,6 +722,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
         f32x16 ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
         f32x16 ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[KS], xa, zero16, 0, 0, 0);
         f32x16 az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[KS], xa, zero16, 0, 0, 0);
+        const f32x16 ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, zero16, 0, 0, 0);   // the candidate's input projection
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const half8 hf = *reinterpret_cast<const half8 *>(arow + 16 * k);
@@ -733,19 +747,11 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
         f32x4 dpl = zero4;
         if (t > 0) dpl = dense_issue(hcur, lcur);
         if (t > 1) finish_step(t - 2);
-#pragma unroll
-        for (int i = 0; i < 16; i += 2) {                                          // r * (h.U_h + b_rec_h)
-            const f32x2 pr = f32x2{ ag[i], ag[i + 1] } * rcp1p_exp2_pair(ar[i], ar[i + 1]);
-            ag[i] = pr.x; ag[i + 1] = pr.y;
-        }
-        ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, ag, 0, 0, 0);            // + x.W_h + b_in_h
         if (t > 0) dense_store(t - 1, dpl);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x2 z = rcp1p_exp2_pair(az[2 * i] - p.zfold, az[2 * i + 1] - p.zfold);
-            const f32x2 hh = 1.0f - 2.0f * rcp1p_exp2_pair(ag[2 * i], ag[2 * i + 1]);
-            h[i] = hh + z * (h[i] - hh);                                             // z*h + (1-z)*hh
-        }
+        for (int i = 0; i < 8; ++i)
+            h[i] = split_gate(f32x2{ ar[2 * i], ar[2 * i + 1] }, f32x2{ ag[2 * i], ag[2 * i + 1] }, f32x2{ az[2 * i], az[2 * i + 1] },
+                              f32x2{ ax[2 * i], ax[2 * i + 1] }, h[i], p.zfold);
         // publish h_t as an fp16 pair: hi = fp16(h), lo = fp16(h - hi)
         _Float16 *wrow = hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
         _Float16 *wlow = lnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
@@ -1375,11 +1381,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     };
     // gate math of elements 2i, 2i+1 of a tile whose pre-activations are complete
     auto gate_piece = [&](tile_state &X, int i) {
-        const f32x2 rr = rcp1p_exp2_pair(X.ar[2 * i], X.ar[2 * i + 1]);
-        const f32x2 g = f32x2{ X.ax[2 * i], X.ax[2 * i + 1] } + rr * f32x2{ X.ag[2 * i], X.ag[2 * i + 1] };
-        const f32x2 hh = 1.0f - 2.0f * rcp1p_exp2_pair(g.x, g.y);
-        const f32x2 z = rcp1p_exp2_pair(X.az[2 * i] - p.zfold, X.az[2 * i + 1] - p.zfold);
-        X.h[i] = hh + z * (X.h[i] - hh);
+        X.h[i] = split_gate(f32x2{ X.ar[2 * i], X.ar[2 * i + 1] }, f32x2{ X.ag[2 * i], X.ag[2 * i + 1] },
+                            f32x2{ X.az[2 * i], X.az[2 * i + 1] }, f32x2{ X.ax[2 * i], X.ax[2 * i + 1] }, X.h[i], p.zfold);
     };
     auto publish = [&](tile_state &X) {
         _Float16 *wrow = X.hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
@@ -1564,7 +1567,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     if (split) {
         // 128-unit class: two row tiles per wave, all fragments resident (no L2 stream) when two carves fit the CU's LDS
         const int half_bytes = (int)dgrp_align_up((int64_t)lds, 256);
-        static const bool one_tile = getenv("DGRP_SPLIT_ONE_TILE") != nullptr;
+        const bool one_tile = getenv("DGRP_SPLIT_ONE_TILE") != nullptr;      // A/B and tests: keep the one-tile kernel
         if (m->NW == 4 && 2 * half_bytes <= 160 * 1024 && groups >= 2 && !one_tile)
             return mode == 0 ? launch_split2<0>(p, groups, half_bytes, stream) : launch_split2<1>(p, groups, half_bytes, stream);
         switch (m->NW) {

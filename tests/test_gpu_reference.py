@@ -194,3 +194,35 @@ def test_cli_precise(tmp_path, orc):
     r = subprocess.run([sys.executable, "-m", "deepgrp_amd", "predict", model, str(fa), "--precise", "--fast"],
                        cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "exclude" in r.stderr
+
+
+@pytest.mark.parametrize("u", [97, 128])
+def test_two_tile_and_one_tile_split_kernels_agree(dev, orc, u, monkeypatch):
+    """The 128-unit class runs `gru_split2_kernel` (two row tiles per wave, 32 windows per workgroup) on single-record
+    launches and `gru_split_kernel` on batched ones; DGRP_SPLIT_ONE_TILE keeps the latter everywhere.  Window counts
+    around the 16 / 32 boundaries exercise the empty second tile and the partial last workgroup; both forms must agree
+    with each other BIT FOR BIT (a record's calls must not depend on how it was batched: tools/fuzz_cli.py found a tie
+    that flipped when they rounded differently) and with the float64 statement."""
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel
+    rng = np.random.default_rng(u)
+    T, s = 40, 7
+    w = orc.Weights.random(u, 5, T, False, seed=4, gain=2.0)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T)
+    assert dm.kernel_flags & 2
+    for nw in (1, 15, 16, 17, 31, 32, 33, 48, 49, 100):
+        idx = _idx(rng, T + s * nw + 3)
+        d = torch.from_numpy(idx).to(dev)
+        two = dm.forward_windows(d, s, 0, nw).cpu().numpy()
+        monkeypatch.setenv("DGRP_SPLIT_ONE_TILE", "1")
+        one = dm.forward_windows(d, s, 0, nw).cpu().numpy()
+        monkeypatch.delenv("DGRP_SPLIT_ONE_TILE")
+        want = orc.nn_forward(idx, w, s, 0, nw, np.float64)
+        assert np.array_equal(two, one) and np.abs(two - want).max() < 1e-5, nw
+        # merged output (MODE 0) incl. the reference's batch placement, against the one-tile form
+        pipe = ContigPipeline(dm, s, 4, 50, 50, True)
+        m2 = pipe.merged(d).cpu().numpy()
+        monkeypatch.setenv("DGRP_SPLIT_ONE_TILE", "1")
+        m1 = pipe.merged(d).cpu().numpy()
+        monkeypatch.delenv("DGRP_SPLIT_ONE_TILE")
+        assert np.array_equal(m2, m1), nw
+    dm.close()
