@@ -104,12 +104,12 @@ class CommandLineParser:
         verify.add_argument("FASTA", nargs="*", type=str, help="Fasta input files; none = a random ACGT sequence")
         verify.add_argument("--windows", type=int, default=256, help="windows to compare per record (spread evenly)")
         predict.add_argument("--fast", action="store_true",
-                             help="(addition) fp16-operand fused kernel for every model: 2.5x the default's speed on GRU models "
-                                  "without attention, class probabilities within 1e-3 of fp32 except on ill-conditioned windows "
+                             help="(addition) fp16-operand fused kernel for every model: 2-2.5x the default's speed on GRU models up to 128 "
+                                  "units, class probabilities within 1e-3 of fp32 except on ill-conditioned windows "
                                   "(measure with `verify`)")
         predict.add_argument("--precise", action="store_true",
-                             help="(addition) fp32-grade forward pass for every model: models the split-operand kernel does not "
-                                  "cover (attention, LSTM, > 128 units) go through plain-fp32 kernels, about 30 Mbp/s")
+                             help="(addition) plain-fp32 forward pass for the models the split-operand kernel does not cover completely "
+                                  "(attention, LSTM, > 128 units), about 30 Mbp/s")
         predict.add_argument("--split_contigs", action="store_true",
                              help="multi-GPU only: spread the windows of EVERY record over all GPUs (for a few huge "
                                   "records) instead of sharding whole records")

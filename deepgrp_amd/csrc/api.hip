@@ -271,7 +271,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
         // the north star whatever the model's conditioning.  dgrp_model_set_precision(m, 0) or
         // DGRP_GRU_PRECISION=0 selects the 2.5x faster fp16-operand kernel.
         const char *pe = getenv("DGRP_GRU_PRECISION");
-        m->precision = (!attention && !(pe && pe[0] == '0')) ? 1 : 0;
+        m->precision = !(pe && pe[0] == '0') ? 1 : 0;
     }
 #undef CREATE_HIP
     *out = m;
@@ -366,8 +366,8 @@ DGRP_EXPORT int dgrp_model_set_precision(dgrp_model *m, int level)
 {
     DGRP_REQUIRE(m, "dgrp_model_set_precision: NULL model");
     DGRP_REQUIRE(level == 0 || level == 1, "dgrp_model_set_precision: level must be 0 (fp16 operands) or 1 (split operands)");
-    DGRP_REQUIRE(level == 0 || (m->cell == 0 && !m->attention && m->d_pack_lo),
-                 "dgrp_model_set_precision: the split-operand kernel covers GRU models without attention up to 128 units");
+    DGRP_REQUIRE(level == 0 || (m->cell == 0 && m->d_pack_lo),
+                 "dgrp_model_set_precision: the split-operand kernel covers GRU models up to 128 units");
     m->precision = level;
     return DGRP_OK;
 }

@@ -617,6 +617,18 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 #endif
 }
 
+// attention pre-pass of the split-operand kernels: avg[t] of this wave's 32 units for window (lane & 15), summed from the
+// hi and lo halves of both strands and stored as fp16 like the fp16-operand kernel does (the second kernel's operand)
+__device__ __forceinline__ void split_avg_store(const gru_params &p, int64_t wg_w, int tt, int UP, int wave, half8 a0, half8 a1,
+                                                half8 l0, half8 l1)
+{
+    const int lane = threadIdx.x & 63;
+    // packed fp16 arithmetic (the halvings are exact; one rounding per add): a quarter of the instructions of a float detour
+    const _Float16 hf = (_Float16)0.5f;
+    const half8 av = (a0 * hf + a1 * hf) + (l0 + l1) * hf;
+    *reinterpret_cast<half8 *>(p.avg + ((wg_w + (lane & 15) - p.w0 + p.avgw) * (int64_t)p.T + tt) * UP + 32 * wave + 8 * (lane >> 4)) = av;
+}
+
 // Gate math of two adjacent units of the split-operand kernels, written once with explicit fused multiply-adds so that
 // the one-tile and the two-tile kernel (batched records vs. single records of the 128-unit class) round identically:
 // a record must not change its calls with the way it was batched.
@@ -637,7 +649,7 @@ __device__ __forceinline__ f32x2 split_gate(f32x2 ar, f32x2 ag, f32x2 az, f32x2 
 // half idle in the fast kernel, becomes the bound.  U_hi stays resident in VGPRs; the U_lo fragments stream from L2
 // every step through a small register ring in consumption order (k-step major, gates r, g, z); the hidden tile's two
 // fragments are read from LDS once per k-step.  Dense takes the lo tile too.  Written for correctness first: no staging of the softmax into
-// MFMA gaps, two reciprocals.  GRU without attention, up to 128 units.
+// MFMA gaps, two reciprocals.  GRU up to 128 units (MODE 2 = the attention pre-pass).
 template <int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params pin)
 {
@@ -687,9 +699,11 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
         }
     };
     const int doff = (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
-    auto dense_issue = [&](const _Float16 *hb, const _Float16 *lb) -> f32x4 {
+    auto dense_issue = [&](const _Float16 *hb, const _Float16 *lb, int tt) -> f32x4 {
         const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff), a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
         const half8 l0 = *reinterpret_cast<const half8 *>(lb + doff), l1 = *reinterpret_cast<const half8 *>(lb + doff + 16 * HS);
+        if (MODE == 2 && (lane & 15) < ctx.nvalid)
+            split_avg_store(p, ctx.wg_w, tt, UP, wave, a0, a1, l0, l1);
         f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
@@ -745,7 +759,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
             az = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[2], hf, az, 0, 0, 0);
         }
         f32x4 dpl = zero4;
-        if (t > 0) dpl = dense_issue(hcur, lcur);
+        if (t > 0) dpl = dense_issue(hcur, lcur, t - 1);
         if (t > 1) finish_step(t - 2);
         if (t > 0) dense_store(t - 1, dpl);
 #pragma unroll
@@ -769,7 +783,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
         tmp = lcur; lcur = lnxt; lnxt = tmp;
     }
     {
-        const f32x4 dpl = dense_issue(hcur, lcur);
+        const f32x4 dpl = dense_issue(hcur, lcur, T - 1);
         if (T > 1) finish_step(T - 2);
         dense_store(T - 1, dpl);
         __syncthreads();
@@ -1364,9 +1378,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             finish_register<NW, MODE>(p, ctx, t, reg, fbias, ctx.rowoff[wi], ctx.row0s[wi]);
         }
     };
-    auto dense_issue = [&](const _Float16 *hb, const _Float16 *lb) -> f32x4 {
+    auto dense_issue = [&](const wg_ctx &ctx, const _Float16 *hb, const _Float16 *lb, int tt) -> f32x4 {
         const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff), a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
         const half8 l0 = *reinterpret_cast<const half8 *>(lb + doff), l1 = *reinterpret_cast<const half8 *>(lb + doff + 16 * HS);
+        if (MODE == 2 && (lane & 15) < ctx.nvalid)
+            split_avg_store(p, ctx.wg_w, tt, UP, wave, a0, a1, l0, l1);
         f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
@@ -1439,7 +1455,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             hf = hfn; lf = lfn;
         }
         X.dpl = zero4;
-        if (t > 0) X.dpl = dense_issue(X.hcur, X.lcur);           // Dense(t-1) from the tile that is in LDS anyway
+        if (t > 0) X.dpl = dense_issue(X.ctx, X.hcur, X.lcur, t - 1);   // Dense(t-1) from the tile that is in LDS anyway
     };
 
     // prologue: tile 0, step 0
@@ -1464,7 +1480,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         __syncthreads();
     }
     auto drain = [&](tile_state &X) {
-        const f32x4 dpl = dense_issue(X.hcur, X.lcur);
+        const f32x4 dpl = dense_issue(X.ctx, X.hcur, X.lcur, T - 1);
         if (T > 1) finish_step(X.ctx, T - 2);
         dense_store(X.ctx, T - 1, dpl);
         __syncthreads();
@@ -1495,18 +1511,21 @@ static int launch_split(const gru_params &p, int64_t groups, size_t lds, hipStre
     if (!configured) {
         DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
     if (p.mode == 0)
         hipLaunchKernelGGL((gru_split_kernel<NW, 0>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
-    else
+    else if (p.mode == 1)
         hipLaunchKernelGGL((gru_split_kernel<NW, 1>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+    else
+        hipLaunchKernelGGL((gru_split_kernel<NW, 2>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
 }
 
 // split-operand kernel selected (dgrp_model_set_precision) and applicable to this launch
-static bool use_split(const dgrp_model *m, int mode) { return m->precision == 1 && m->cell == 0 && m->NW <= 4 && mode != 2 && m->d_pack_lo; }
+static bool use_split(const dgrp_model *m, int) { return m->precision == 1 && m->cell == 0 && m->NW <= 4 && m->d_pack_lo; }
 
 template <int NW>
 static int launch_lstm(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
@@ -1569,7 +1588,8 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
         const int half_bytes = (int)dgrp_align_up((int64_t)lds, 256);
         const bool one_tile = getenv("DGRP_SPLIT_ONE_TILE") != nullptr;      // A/B and tests: keep the one-tile kernel
         if (m->NW == 4 && 2 * half_bytes <= 160 * 1024 && groups >= 2 && !one_tile)
-            return mode == 0 ? launch_split2<0>(p, groups, half_bytes, stream) : launch_split2<1>(p, groups, half_bytes, stream);
+            return mode == 0 ? launch_split2<0>(p, groups, half_bytes, stream)
+                 : mode == 1 ? launch_split2<1>(p, groups, half_bytes, stream) : launch_split2<2>(p, groups, half_bytes, stream);
         switch (m->NW) {
         case 1: return launch_split<1>(p, groups, lds, stream);
         case 2: return launch_split<2>(p, groups, lds, stream);

@@ -118,8 +118,9 @@ class DeviceModel:
 
     @property
     def supports_split(self) -> bool:
-        """The split-operand fused kernel (fp16 hi+lo pairs, fp32-grade pre-activations) covers this model."""
-        return self.rnn == "GRU" and not self.attention and self.units <= 128
+        """The split-operand fused kernel (fp16 hi+lo pairs, fp32-grade pre-activations) covers this model (with
+        attention: its recurrent pre-pass)."""
+        return self.rnn == "GRU" and self.units <= 128
 
     def set_precision(self, level: int) -> None:
         """dgrp_model_set_precision: 0 = fp16 operands (default), 1 = split operands, for every later call."""
@@ -244,15 +245,19 @@ class ContigPipeline:
         self.use_mss = bool(use_mss)
         self.chunk_windows = int(chunk_windows)
         # Which forward kernel runs ("accuracy"):
-        #   default  the split-operand fused kernel where it exists (GRU without attention, <= 128 units: every base within
-        #            ~1e-6 of fp32), the fp16-operand fused kernel for the other models;
+        #   default  the split-operand fused kernel where it exists (GRU, <= 128 units: every base within ~1e-6 of fp32,
+        #            ~1e-5 with attention), the fp16-operand fused kernel for the other models;
         #   fast     the fp16-operand fused kernel everywhere (2.5x faster; 1e-3 on all but ill-conditioned windows);
-        #   precise  like default, but models without a split kernel go through the plain-fp32 kernels (30 Mbp/s).
+        #   precise  like default, but attention models and models without a split kernel go through the plain-fp32
+        #            kernels (30 Mbp/s).
         if precise and fast:
             raise ValueError("precise and fast exclude each other")
         self.precise, self.fast = bool(precise), bool(fast)
-        self.split = not self.fast and bool(getattr(model, "supports_split", False))
-        self.fp32 = self.precise and not self.split
+        can_split = bool(getattr(model, "supports_split", False))
+        # attention models keep avg[t] as fp16 between their two kernels even with the split pre-pass (1e-5-level, not
+        # amplified by the recurrence): `precise` sends them through the fp32 kernels all the same
+        self.fp32 = self.precise and (not can_split or bool(getattr(model, "attention", False)))
+        self.split = not self.fast and can_split and not self.fp32
         self.event_log = None        # bench.py: list collecting (start, end, windows) per GRU launch
         if self.step < 1 or self.batch < 1:
             raise ValueError("step_size and batch_size must be >= 1")

@@ -117,7 +117,8 @@ int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int *attention)
 int dgrp_model_flags(const dgrp_model *m);
 /* (addition) Precision of the recurrent contraction for every later call on this model: 0 = fp16 MFMA operands (default,
  * the benchmarked path); 1 = split operands: weights and hidden state as fp16 hi+lo pairs, three MFMA passes, fp32-grade
- * pre-activations (GRU without attention, <= 128 units; DGRP_EINVAL otherwise).  dgrp_model_flags bit 1 reports it. */
+ * pre-activations (GRU, <= 128 units -- with attention it is the recurrent pre-pass that runs split, avg[t] still crosses to the second
+ * kernel as fp16; DGRP_EINVAL for LSTM and larger models).  dgrp_model_flags bit 1 reports it. */
 int dgrp_model_set_precision(dgrp_model *m, int level);
 
 /* ---- A4: model.predict_on_batch (deepgrp/prediction.py:106)

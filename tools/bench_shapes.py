@@ -19,9 +19,11 @@ for name, u, T, s, att, n in cases:
     w = synthetic.synthetic_weights(u, 5, att, seed=7, gain=1.5)
     m = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], T)
     st, d_idx = upload_sequence(synthetic.synthetic_chromosome(int(n)))
-    pipe = ContigPipeline(m, s)
-    pipe.merged(d_idx); torch.cuda.synchronize()
-    t0 = time.perf_counter(); pipe.merged(d_idx); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     fl = (12 * u * u * T + 2 * (2 * u if att else u) * 5 * T + (6 * u * T if att else 0)) / s
-    print(f"{name:52s} {n/1e6:4.0f} Mbp: {dt*1e3:8.1f} ms  {n/dt/1e6:7.1f} Mbp/s  {fl*n/dt/1e12:6.1f} TFLOP/s", flush=True)
+    for fast in ((False, True) if m.supports_split else (True,)):       # default (split operands where they exist) and --fast
+        pipe = ContigPipeline(m, s, fast=fast)
+        pipe.merged(d_idx); torch.cuda.synchronize()
+        t0 = time.perf_counter(); pipe.merged(d_idx); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        kind = "split" if pipe.split else "fp16 "
+        print(f"{name:52s} {kind} {n/1e6:4.0f} Mbp: {dt*1e3:8.1f} ms  {n/dt/1e6:7.1f} Mbp/s  {fl*n/dt/1e12:6.1f} TFLOP/s", flush=True)
     m.close(); del d_idx, pipe; torch.cuda.empty_cache()

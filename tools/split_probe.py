@@ -8,9 +8,11 @@ from oracle import oracle as orc
 _st, d_idx = upload_sequence(synthetic.synthetic_chromosome(200 + 50 * 2048 + 1000, contig=0, flank=500))
 idx = d_idx.cpu().numpy()
 for name, w in (("trained", synthetic.trained_weights()), ("gain3", synthetic.synthetic_weights(128, 5, False, 7, 3.0)),
-                ("u60", synthetic.synthetic_weights(60, 5, False, 3, 2.0)), ("u20", synthetic.synthetic_weights(20, 5, False, 3, 2.0))):
+                ("u60", synthetic.synthetic_weights(60, 5, False, 3, 2.0)), ("u20", synthetic.synthetic_weights(20, 5, False, 3, 2.0)),
+                ("att128g2", synthetic.synthetic_weights(128, 5, True, 9, 2.0)), ("att128g3", synthetic.synthetic_weights(128, 5, True, 5, 3.0)),
+                ("att60", synthetic.synthetic_weights(60, 5, True, 3, 1.0))):
     dm = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=200)
-    ow = orc.Weights(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, 200)
+    ow = orc.Weights(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], 200)
     o = orc.nn_forward(idx, ow, 50, 0, 64, np.float64)
     for level in (0, 1):
         dm.set_precision(level)
