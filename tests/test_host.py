@@ -171,6 +171,30 @@ def test_reverse_complement_layer():
     np.testing.assert_equal(layer(layer(x)), x)
 
 
+def test_pipeline_kernel_selection_table():
+    """Which forward kernel a pipeline uses: split operands by default where the model has them, fp16
+    operands with fast=True or where it has not, plain fp32 with precise=True for attention models and models without
+    a split kernel."""
+    from types import SimpleNamespace
+    from deepgrp_amd.pipeline import ContigPipeline
+    gru = SimpleNamespace(supports_split=True, attention=False)
+    att = SimpleNamespace(supports_split=True, attention=True)
+    big = SimpleNamespace(supports_split=False, attention=False)          # LSTM, or more than 128 units
+    table = {  # (model, precise, fast) -> (split, fp32)
+        (0, False, False): (True, False), (0, True, False): (True, False), (0, False, True): (False, False),
+        (1, False, False): (True, False), (1, True, False): (False, True), (1, False, True): (False, False),
+        (2, False, False): (False, False), (2, True, False): (False, True), (2, False, True): (False, False),
+    }
+    for (mi, precise, fast), (split, fp32) in table.items():
+        pipe = ContigPipeline((gru, att, big)[mi], 50, 256, 50, 50, True, precise=precise, fast=fast)
+        assert (pipe.split, pipe.fp32) == (split, fp32), (mi, precise, fast)
+        assert pipe.batchable() == (not fp32)
+    with pytest.raises(ValueError, match="exclude"):
+        ContigPipeline(gru, precise=True, fast=True)
+    with pytest.raises(ValueError):
+        ContigPipeline(gru, step_size=0)
+
+
 def test_create_model_config_matches_the_reference_fixture():
     """tests/test_model.py:254-262 of the reference: create_model(Options(attention=True, rnn=rnn)).get_config() equals
     the stored config of its TensorFlow minor version -- 2.5 here, the version its poetry.lock pins (fixture copied
