@@ -228,3 +228,19 @@ def test_two_tile_and_one_tile_split_kernels_agree(dev, orc, u, monkeypatch):
         monkeypatch.delenv("DGRP_SPLIT_ONE_TILE")
         assert np.array_equal(m2, m1), nw
     dm.close()
+
+
+def test_long_windows_at_128_units(dev, orc):
+    """128 units with windows so long that two LDS carves no longer fit a CU: the launcher falls back to the one-tile
+    split kernel; same numbers as the two-tile kernel gives on the windows that do fit, both against the float64
+    statement."""
+    from deepgrp_amd.pipeline import DeviceModel
+    rng = np.random.default_rng(12)
+    for T, nw in ((1500, 33), (3000, 18)):                       # 1500: two tiles fit; 3000: they do not
+        w = orc.Weights.random(128, 5, T, False, seed=2, gain=1.0)
+        dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=T)
+        idx = _idx(rng, T + 16 * nw)
+        got = dm.forward_windows(torch.from_numpy(idx).to(dev), 16, 0, nw).cpu().numpy()
+        want = orc.nn_forward(idx, w, 16, 0, nw, np.float64)
+        assert np.abs(got - want).max() < 1e-5, T
+        dm.close()
