@@ -156,13 +156,13 @@ struct wg_ctx {                       // LDS carve of a workgroup and what its 1
 // batched records: rewrite the launch-wide parameters into those of the record this workgroup belongs to (last r with
 // wg_first[r] <= blockIdx.x; uniform over the workgroup: scalar loads) and return the workgroup's index inside it
 template <int MODE>
-__device__ __forceinline__ int64_t wg_record(const gru_params &pin, gru_params &p)
+__device__ __forceinline__ int64_t wg_record_at(const gru_params &pin, gru_params &p, int64_t g)
 {
-    if (MODE == 1 || !pin.recs) return blockIdx.x;
+    if (MODE == 1 || !pin.recs) return g;
     int64_t lo_r = 0, hi_r = pin.nrec;
     while (hi_r - lo_r > 1) {
         const int64_t mid = (lo_r + hi_r) >> 1;
-        if (pin.wg_first[mid] <= (int64_t)blockIdx.x) lo_r = mid; else hi_r = mid;
+        if (pin.wg_first[mid] <= g) lo_r = mid; else hi_r = mid;
     }
     const gru_rec rc = pin.recs[lo_r];
     p.idx = pin.idx + rc.idx_off;
@@ -172,8 +172,10 @@ __device__ __forceinline__ int64_t wg_record(const gru_params &pin, gru_params &
     p.w0 = 0;
     p.nw = rc.nwin;
     p.avgw = rc.win_first;
-    return (int64_t)blockIdx.x - pin.wg_first[lo_r];
+    return g - pin.wg_first[lo_r];
 }
+template <int MODE>
+__device__ __forceinline__ int64_t wg_record(const gru_params &pin, gru_params &p) { return wg_record_at<MODE>(pin, p, blockIdx.x); }
 
 // carve, stage the windows' sequences, zero the state and the image, work out the placement (ends with a barrier)
 template <int NW, int MODE>
@@ -1316,16 +1318,16 @@ static int launch_gru(const gru_params &p, int64_t groups, size_t lds, bool oner
 // carve of a 16-window workgroup (`half_bytes` apart), so the shared helpers apply unchanged with workgroup index
 // 2 * blockIdx.x + tile.
 template <int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gru_split2_kernel(const gru_params p, int half_bytes)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gru_split2_kernel(const gru_params pin, int half_bytes)
 {
     constexpr int NW = 4, UP = 128, KS = 8, HS = UP + 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = p.T, C = p.C;
-    const uint4 *mypack = p.pack + (size_t)wave * p.nfrag * 64 + lane;
-    const uint4 *mylo = p.pack_lo + (size_t)wave * 3 * KS * 64 + lane;
+    const int T = pin.T, C = pin.C;
+    const uint4 *mypack = pin.pack + (size_t)wave * pin.nfrag * 64 + lane;
+    const uint4 *mylo = pin.pack_lo + (size_t)wave * 3 * KS * 64 + lane;
     half8 Bz[KS + 1], Br[KS + 1], Bg[KS + 1], Lr[KS], Lg[KS], Lz[KS], Bxh, Bd_hi, Bd_lo;
 #pragma unroll
     for (int k = 0; k <= KS; ++k) {
@@ -1344,6 +1346,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 2) * 64]);
 
     struct tile_state {
+        gru_params p;                     // batched records: the two tiles may belong to different records
         wg_ctx ctx;
         _Float16 *hcur, *hnxt, *lcur, *lnxt;
         const uint8_t *myseq;
@@ -1355,12 +1358,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int r = lane & 31, wi_a = r & 15, dir = r >> 4, khalf = lane >> 5;
     auto setup = [&](tile_state &X, int x) {
         unsigned char *base = smem + (size_t)x * half_bytes;
-        _Float16 *lbuf = reinterpret_cast<_Float16 *>(base + p.lo_tile_off);
+        _Float16 *lbuf = reinterpret_cast<_Float16 *>(base + pin.lo_tile_off);
         for (int i = tid; i < 32 * HS; i += 256) lbuf[i] = (_Float16)0.0f;
-        X.ctx = wg_setup<NW, MODE>(p, base, 2 * (int64_t)blockIdx.x + x);             // ends with a barrier
+        X.p = pin;
+        const int64_t bid = wg_record_at<MODE>(pin, X.p, 2 * (int64_t)blockIdx.x + x);
+        X.ctx = wg_setup<NW, MODE>(X.p, base, bid);                                    // ends with a barrier
         X.hcur = X.ctx.hbuf; X.hnxt = X.ctx.hbuf + 32 * HS;
         X.lcur = lbuf; X.lnxt = lbuf + 32 * HS;
-        X.myseq = X.ctx.seqs + wi_a * p.Tp;
+        X.myseq = X.ctx.seqs + wi_a * pin.Tp;
 #pragma unroll
         for (int i = 0; i < 8; ++i) X.h[i] = f32x2{ 0.0f, 0.0f };
     };
@@ -1369,20 +1374,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     const f32x4 zero4 = { 0, 0, 0, 0 };
     const int cls = lane & 15;
-    const float fbias = cls < C ? p.ffb[cls] : 0.0f;
+    const float fbias = cls < C ? pin.ffb[cls] : 0.0f;
     const int doff = (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
 
-    auto finish_step = [&](const wg_ctx &ctx, int t) {
+    auto finish_step = [&](const tile_state &X, int t) {
         for (int reg = wave; reg < 4; reg += NW) {
             const int wi = 4 * (lane >> 4) + reg;
-            finish_register<NW, MODE>(p, ctx, t, reg, fbias, ctx.rowoff[wi], ctx.row0s[wi]);
+            finish_register<NW, MODE>(X.p, X.ctx, t, reg, fbias, X.ctx.rowoff[wi], X.ctx.row0s[wi]);
         }
     };
-    auto dense_issue = [&](const wg_ctx &ctx, const _Float16 *hb, const _Float16 *lb, int tt) -> f32x4 {
+    auto dense_issue = [&](const tile_state &X, const _Float16 *hb, const _Float16 *lb, int tt) -> f32x4 {
         const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff), a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
         const half8 l0 = *reinterpret_cast<const half8 *>(lb + doff), l1 = *reinterpret_cast<const half8 *>(lb + doff + 16 * HS);
-        if (MODE == 2 && (lane & 15) < ctx.nvalid)
-            split_avg_store(p, ctx.wg_w, tt, UP, wave, a0, a1, l0, l1);
+        if (MODE == 2 && (lane & 15) < X.ctx.nvalid)
+            split_avg_store(X.p, X.ctx.wg_w, tt, UP, wave, a0, a1, l0, l1);
         f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
@@ -1398,7 +1403,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // gate math of elements 2i, 2i+1 of a tile whose pre-activations are complete
     auto gate_piece = [&](tile_state &X, int i) {
         X.h[i] = split_gate(f32x2{ X.ar[2 * i], X.ar[2 * i + 1] }, f32x2{ X.ag[2 * i], X.ag[2 * i + 1] },
-                            f32x2{ X.az[2 * i], X.az[2 * i + 1] }, f32x2{ X.ax[2 * i], X.ax[2 * i + 1] }, X.h[i], p.zfold);
+                            f32x2{ X.az[2 * i], X.az[2 * i + 1] }, f32x2{ X.ax[2 * i], X.ax[2 * i + 1] }, X.h[i], pin.zfold);
     };
     auto publish = [&](tile_state &X) {
         _Float16 *wrow = X.hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
@@ -1455,7 +1460,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             hf = hfn; lf = lfn;
         }
         X.dpl = zero4;
-        if (t > 0) X.dpl = dense_issue(X.ctx, X.hcur, X.lcur, t - 1);   // Dense(t-1) from the tile that is in LDS anyway
+        if (t > 0) X.dpl = dense_issue(X, X.hcur, X.lcur, t - 1);   // Dense(t-1) from the tile that is in LDS anyway
     };
 
     // prologue: tile 0, step 0
@@ -1465,7 +1470,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         contract(S1, t, S0, true);
         if (t > 0) dense_store(S0.ctx, t - 1, S0.dpl);
         publish(S0);
-        if (t > 1) finish_step(S0.ctx, t - 2);
+        if (t > 1) finish_step(S0, t - 2);
         __syncthreads();                                          // tile 0: h_t and the Dense(t-1) partials are in LDS
         // tile 0's step t+1  ||  tile 1's gate math of step t
         if (t + 1 < T) {
@@ -1476,16 +1481,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
         if (t > 0) dense_store(S1.ctx, t - 1, S1.dpl);
         publish(S1);
-        if (t > 1) finish_step(S1.ctx, t - 2);
+        if (t > 1) finish_step(S1, t - 2);
         __syncthreads();
     }
     auto drain = [&](tile_state &X) {
-        const f32x4 dpl = dense_issue(X.ctx, X.hcur, X.lcur, T - 1);
-        if (T > 1) finish_step(X.ctx, T - 2);
+        const f32x4 dpl = dense_issue(X, X.hcur, X.lcur, T - 1);
+        if (T > 1) finish_step(X, T - 2);
         dense_store(X.ctx, T - 1, dpl);
         __syncthreads();
-        finish_step(X.ctx, T - 1);
-        if (MODE == 0 && p.ospan > 0) flush_image<NW>(p, X.ctx);
+        finish_step(X, T - 1);
+        if (MODE == 0 && pin.ospan > 0) flush_image<NW>(X.p, X.ctx);
     };
     drain(S0);
     drain(S1);
@@ -1661,6 +1666,9 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T, fixed);
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
     if (split) {
+        const int half_bytes = (int)dgrp_align_up((int64_t)lds, 256);
+        if (m->NW == 4 && 2 * half_bytes <= 160 * 1024 && total_groups >= 2 && !getenv("DGRP_SPLIT_ONE_TILE"))
+            return mode == 0 ? launch_split2<0>(p, total_groups, half_bytes, stream) : launch_split2<2>(p, total_groups, half_bytes, stream);
         switch (m->NW) {
         case 1: return launch_split<1>(p, total_groups, lds, stream);
         case 2: return launch_split<2>(p, total_groups, lds, stream);

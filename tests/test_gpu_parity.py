@@ -139,7 +139,7 @@ def test_forward_windows_vs_oracle(dev, orc, u, T, attention, gain, s, nw):
     # both fused kernels: fp16 operands (the fast mode; the default for models without a split kernel) to 1e-3, split
     # operands (the default where it exists) to fp32 rounding
     # (with attention avg[t] still crosses to the second kernel as fp16: 1e-5-level, not amplified by the recurrence)
-    for level, tol in ((0, 1e-3),) + (((1, 1e-4 if attention else 1e-5),) if dm.supports_split else ()):
+    for level, tol in ((0, 1e-3),) + (((1, 3e-4 if attention else 1e-5),) if dm.supports_split else ()):
         dm.set_precision(level)
         assert bool(dm.kernel_flags & 2) == bool(level)
         got = dm.forward_windows(_t(idx, dev), s, 2, nw).cpu().numpy()

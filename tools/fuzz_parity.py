@@ -58,7 +58,7 @@ while time.time() < t_end:
                 err = float(np.abs(got - want).max())
                 if pipe.split:
                     worst_split = max(worst_split, err)
-                    assert err < (1e-4 if att else 1e-5), f"forward error {err} (split operands)"
+                    assert err < (3e-4 if att else 1e-5), f"forward error {err} (split operands)"   # attention: fp16 avg[t] between the kernels
                 else:
                     worst = max(worst, err)
                     assert err < 1e-3, f"forward error {err}"
