@@ -179,6 +179,8 @@ class CommandLineParser:
         pipe = ContigPipeline(model, args.step_size, options.batch_size, options.min_mss_len, options.xdrop_len,
                               use_mss=not args.no_use_mss, precise=getattr(args, "precise", False),
                               fast=getattr(args, "fast", False))
+        _LOG.info("Forward kernel: %s", "plain fp32 kernels (--precise)" if pipe.fp32 else
+                  "fused, split operands (fp32-grade)" if pipe.split else "fused, fp16 operands")
         if pipe.fp32 and getattr(args, "split_contigs", False):
             sys.exit("--precise is not combined with --split_contigs for this model")
         outstream = None
