@@ -33,6 +33,16 @@
 // (5-6 transcendentals and ~8 plain operations per (row, unit, step)): a wave issues
 // in order and waits for the matrix pipe at every back-to-back MFMA, so the gate math of one chain
 // is placed in the gaps of the next chain in program order; two workgroups per CU share each SIMD.
+//
+// Kernels in this file:
+//   gru_fused_kernel<NW,MODE,ONERCP>  fp16 MFMA operands (dgrp_model_set_precision 0; the only fused GRU kernel beyond 128 units)
+//   gru_split_kernel<NW,MODE>         split operands (U and h as fp16 hi+lo pairs, three MFMA passes): the default up to 128
+//                                     units where two LDS carves do not fit or below 97 units
+//   gru_split2_kernel<MODE>           split operands, 97-128 units: one wave per SIMD, two row tiles per wave, U_hi and U_lo
+//                                     resident (512-register budget)
+//   lstm_fused_kernel<NW,MODE>        rnn = "LSTM", fp16 operands
+//   attention_kernel / attention_wave_kernel<UP,CM>   second pass of attention models (after a MODE 2 pre-pass)
+// MODE 0: forward + max-merge into [n, C]; 1: probabilities [nw, T, C]; 2: attention pre-pass (avg[t] spill + partial logits)
 #include "dgrp_model.h"
 #include <vector>
 
