@@ -43,250 +43,7 @@
 //   lstm_fused_kernel<NW,MODE>        rnn = "LSTM", fp16 operands
 //   attention_kernel / attention_wave_kernel<UP,CM>   second pass of attention models (after a MODE 2 pre-pass)
 // MODE 0: forward + max-merge into [n, C]; 1: probabilities [nw, T, C]; 2: attention pre-pass (avg[t] spill + partial logits)
-#include "dgrp_model.h"
-#include <vector>
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-
-#define DGRP_WG_WINDOWS 16
-
-struct gru_rec {
-    int64_t idx_off, n, out_row, nwin;
-    dgrp_placement place;
-    int64_t win_first;   // windows of the records before this one (row of its first window in the avg / pl spill)
-    int64_t pad_;
-};
-
-struct gru_params {
-    const uint8_t *idx;   // class index per base [n]
-    int64_t n, s, w0, nw; // this launch covers windows w0 .. w0+nw-1 (absolute indices)
-    dgrp_placement place;
-    const uint4 *pack;
-    const float *ffb;
-    float *out;           // mode 0: merged [n, C]; mode 1: probs [nw, T, C]; mode 2: logits part [nw, T, C]
-    _Float16 *avg;        // mode 2: [nw, T, UP] fp16
-    int T, C, nfrag, mode;
-    int Tp;               // T rounded up to 16 (row pitch of the staged sequences)
-    int ospan;            // rows of the LDS output image (mode 0), 0 = none
-    uint64_t *stamps;
-    // batched records (mode 0): workgroup b belongs to record r with wg_first[r] <= b < wg_first[r+1]; idx / out / n /
-    // placement then come from recs[r] and windows count from 0 inside the record
-    const struct gru_rec *recs;
-    const int64_t *wg_first;
-    int64_t nrec;
-    int64_t avgw;         // modes 1, 2: row of window w0 in the output / spill buffers (batched records: the record's first)
-    // split-operand kernel only: the lo halves of the recurrent fragments ([NW][KS][3][64]: k-step major, gates r, g, z), the byte
-    // offset of the lo hidden tiles in the dynamic LDS, and 1.0 if the packed z bias carries the one-reciprocal "+1"
-    const uint4 *pack_lo;
-    int lo_tile_off;
-    float zfold;
-};
-
-// The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
-// so the accumulators feed v_exp_f32 directly:  sigmoid(x) = 1/(1 + 2^(-x log2 e)),
-// tanh(x) = 1 - 2/(1 + 2^(2 x log2 e)).
-__device__ __forceinline__ float sigmoid_from_scaled(float a) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
-__device__ __forceinline__ float tanh_from_scaled(float a) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a)); }
-// Two gate values at a time: the transcendentals are scalar instructions, the "1 +" between them is one
-// packed add (v_pk_add_f32 does two lanes' worth per issue slot).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 rcp1p_exp2_pair(float a0, float a1)
-{
-    f32x2 e = { __builtin_amdgcn_exp2f(a0), __builtin_amdgcn_exp2f(a1) };
-    e = e + 1.0f;
-    return f32x2{ __builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y) };
-}
-__device__ __forceinline__ float fast_tanh(float x) { return tanh_from_scaled(2.8853900817779268f * x); }
-
-// rotate within each row of 16 lanes (DPP row_ror): an all-reduce over the 16 class lanes in 4 steps
-template <int N>
-__device__ __forceinline__ float row_ror(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 | N, 0xf, 0xf, false));
-}
-// max(x, x rotated by N) as ONE v_max_f32_dpp (fmaxf on a DPP move costs a zero fill, the move and two
-// canonicalising maxes); the s_nop covers the VALU-write -> DPP-read hazard the assembler does not see.
-template <int N>
-__device__ __forceinline__ float row_max_ror(float x)
-{
-    float r;
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(N));
-    return r;
-}
-// exchange inside quads: 0x4E = lanes [2,3,0,1] (xor 2), 0xB1 = [1,0,3,2] (xor 1)
-template <int CTRL>
-__device__ __forceinline__ float quad_perm(float x)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float row_allmax(float x)
-{
-    return row_max_ror<1>(row_max_ror<2>(row_max_ror<4>(row_max_ror<8>(x))));
-}
-__device__ __forceinline__ float row_allsum(float x)
-{
-    x += row_ror<8>(x); x += row_ror<4>(x); x += row_ror<2>(x); return x + row_ror<1>(x);
-}
-
-// The two destinations of the max-merge as distinct instructions (ds_max_u32 / global_atomic_umax): left to
-// atomicMax on generic pointers the compiler merges both branches into one flat atomic, whose latency then
-// sits in front of every later LDS wait of the wave.
-typedef __attribute__((address_space(3))) unsigned lds_u32;
-typedef __attribute__((address_space(1))) unsigned glb_u32;
-__device__ __forceinline__ void lds_atomic_max(unsigned *p, unsigned v)
-{
-    (void)__hip_atomic_fetch_max((lds_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void global_atomic_max(unsigned *p, unsigned v)
-{
-    (void)__hip_atomic_fetch_max((glb_u32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// LDS carve (bytes) -- shared by host and device
-__host__ __device__ static inline int gru_lds_hbuf(int UP) { return 2 * 32 * (UP + 8) * 2; }
-__host__ __device__ static inline int gru_lds_dpart(int NW) { return 2 * NW * 64 * 16; }
-__host__ __device__ static inline int gru_lds_seq(int Tp) { return DGRP_WG_WINDOWS * Tp; }
-__host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 8 + DGRP_WG_WINDOWS * 4; }
-
-// ---- pieces shared by the GRU and the LSTM kernel --------------------------------------------------------------
-struct wg_ctx {                       // LDS carve of a workgroup and what its 16 windows are
-    _Float16 *hbuf;                   // [2][32][HS] hidden tile, ping-pong
-    float *dpart;                     // [2][4 regs][NW][64] partial logits of the waves
-    uint8_t *seqs;                    // [16][Tp] class indices of the windows
-    int64_t *row0s;                   // first output row of each window (mode 0: merged row, else row in [nw*T])
-    int *rowoff;                      // mode 0: row in the LDS image, -1 = goes to HBM directly
-    unsigned *obuf;                   // mode 0: max image of the rows the windows cover
-    int64_t wg_w, lo;                 // first window; first row of the image
-    int nvalid;
-};
-
-// batched records: rewrite the launch-wide parameters into those of the record this workgroup belongs to (last r with
-// wg_first[r] <= blockIdx.x; uniform over the workgroup: scalar loads) and return the workgroup's index inside it
-template <int MODE>
-__device__ __forceinline__ int64_t wg_record_at(const gru_params &pin, gru_params &p, int64_t g)
-{
-    if (MODE == 1 || !pin.recs) return g;
-    int64_t lo_r = 0, hi_r = pin.nrec;
-    while (hi_r - lo_r > 1) {
-        const int64_t mid = (lo_r + hi_r) >> 1;
-        if (pin.wg_first[mid] <= g) lo_r = mid; else hi_r = mid;
-    }
-    const gru_rec rc = pin.recs[lo_r];
-    p.idx = pin.idx + rc.idx_off;
-    p.n = rc.n;
-    if (MODE == 0) p.out = pin.out + rc.out_row * pin.C;
-    p.place = rc.place;
-    p.w0 = 0;
-    p.nw = rc.nwin;
-    p.avgw = rc.win_first;
-    return g - pin.wg_first[lo_r];
-}
-template <int MODE>
-__device__ __forceinline__ int64_t wg_record(const gru_params &pin, gru_params &p) { return wg_record_at<MODE>(pin, p, blockIdx.x); }
-
-// carve, stage the windows' sequences, zero the state and the image, work out the placement (ends with a barrier)
-template <int NW, int MODE>
-__device__ __forceinline__ wg_ctx wg_setup(const gru_params &p, unsigned char *smem, int64_t bid)
-{
-    constexpr int UP = 32 * NW, HS = UP + 8;
-    wg_ctx c;
-    c.hbuf = reinterpret_cast<_Float16 *>(smem);
-    c.dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP));
-    c.seqs = smem + gru_lds_hbuf(UP) + gru_lds_dpart(NW);
-    c.row0s = reinterpret_cast<int64_t *>(c.seqs + gru_lds_seq(p.Tp));
-    c.rowoff = reinterpret_cast<int *>(c.row0s + DGRP_WG_WINDOWS);
-    c.obuf = reinterpret_cast<unsigned *>(c.rowoff + DGRP_WG_WINDOWS);
-    const int tid = threadIdx.x, T = p.T, C = p.C;
-    c.wg_w = p.w0 + bid * DGRP_WG_WINDOWS;
-    c.nvalid = (int)min((int64_t)DGRP_WG_WINDOWS, p.w0 + p.nw - c.wg_w);
-    for (int i = tid; i < DGRP_WG_WINDOWS * T; i += 64 * NW) {
-        const int wi = i / T, t = i - wi * T;
-        c.seqs[wi * p.Tp + t] = wi < c.nvalid ? p.idx[(c.wg_w + wi) * p.s + t] : (uint8_t)4;
-    }
-    for (int i = tid; i < 32 * HS; i += 64 * NW) c.hbuf[i] = (_Float16)0.0f;          // h_{-1} = 0
-    c.lo = 0;
-    if (MODE == 0) {
-        // smallest placement row of the two ends (the partial-batch shift keeps rows monotone inside
-        // each regime); windows that fall outside [lo, lo + ospan) go to HBM directly
-        const int64_t a = dgrp_place_row(p.place, c.wg_w, p.s), b = dgrp_place_row(p.place, c.wg_w + c.nvalid - 1, p.s);
-        c.lo = a < b ? a : b;
-        for (int i = tid; i < p.ospan * C; i += 64 * NW) c.obuf[i] = 0u;
-    }
-    if (tid < DGRP_WG_WINDOWS) {
-        int64_t r0 = -1;
-        int off = -1;
-        if (tid < c.nvalid) {
-            r0 = MODE == 0 ? dgrp_place_row(p.place, c.wg_w + tid, p.s) : (c.wg_w + tid - p.w0 + p.avgw) * (int64_t)T;
-            if (MODE == 0 && r0 >= c.lo && r0 - c.lo + T <= p.ospan) off = (int)(r0 - c.lo);
-        }
-        c.row0s[tid] = r0;
-        c.rowoff[tid] = off;
-    }
-    __syncthreads();
-    return c;
-}
-
-// merge (mode 0) or store one finished value of window `wi`, step t, class `cls`
-template <int MODE>
-__device__ __forceinline__ void emit_value(const gru_params &p, const wg_ctx &c, int off, int64_t row0, int t, int cls, float val)
-{
-    if (MODE == 0) {
-        if (off >= 0) {
-            lds_atomic_max(c.obuf + (off + t) * p.C + cls, __float_as_uint(val));
-        } else {
-            const int64_t row = row0 + t;
-            if (row < p.n) global_atomic_max(reinterpret_cast<unsigned *>(p.out) + row * p.C + cls, __float_as_uint(val));
-        }
-    } else {
-        p.out[(row0 + t) * p.C + cls] = val;
-    }
-}
-
-// Softmax + merge of step t's partial logits for accumulator register `reg`: the 16x16 logit tile (window =
-// 4*(lane>>4) + reg, class = lane & 15) is split by register over the waves, one value per lane.
-template <int NW, int MODE>
-__device__ __forceinline__ void finish_register(const gru_params &p, const wg_ctx &c, int t, int reg, float fbias, int off, int64_t row0)
-{
-    const int lane = threadIdx.x & 63, cls = lane & 15;
-    const float *dp = c.dpart + ((size_t)(t & 1) * 4 + reg) * NW * 64 + lane;
-    float sum = dp[0];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) sum += dp[w * 64];
-    const int wi = 4 * (lane >> 4) + reg;
-    const float lg = cls < p.C ? sum + fbias : -INFINITY;
-    float val = lg;
-    if (MODE != 2) {                                  // attention: softmax happens in the second kernel
-        const float m = row_allmax(lg);
-        const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg - m));   // 0 for the padding lanes
-        val = e * __builtin_amdgcn_rcpf(row_allsum(e));
-    }
-    if (cls < p.C && wi < c.nvalid) emit_value<MODE>(p, c, off, row0, t, cls, val);
-}
-
-// flush the pre-merged image: contiguous rows -> 256-byte atomic wave-instructions
-template <int NW>
-__device__ __forceinline__ void flush_image(const gru_params &p, const wg_ctx &c)
-{
-    __syncthreads();
-    unsigned *gout = reinterpret_cast<unsigned *>(p.out) + c.lo * p.C;
-    const int64_t lim = (p.n - c.lo) * p.C;
-    for (int i = threadIdx.x; i < p.ospan * p.C; i += 64 * NW) {
-        const unsigned v = c.obuf[i];
-        if (v != 0u && i < lim) global_atomic_max(gout + i, v);
-    }
-}
-
-#ifdef DGRP_STAMP
-#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const uint64_t now_ = __builtin_amdgcn_s_memtime(); stamp_acc[i] += (uint32_t)(now_ - stamp_prev); stamp_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-#ifndef DGRP_PIPE
-#define DGRP_PIPE 1
-#endif
+#include "gru_shared.h"
 template <int NW, int MODE, bool ONERCP>
 __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params pin)
 {
@@ -629,31 +386,6 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
 #endif
 }
 
-// attention pre-pass of the split-operand kernels: avg[t] of this wave's 32 units for window (lane & 15), summed from the
-// hi and lo halves of both strands and stored as fp16 like the fp16-operand kernel does (the second kernel's operand)
-__device__ __forceinline__ void split_avg_store(const gru_params &p, int64_t wg_w, int tt, int UP, int wave, half8 a0, half8 a1,
-                                                half8 l0, half8 l1)
-{
-    const int lane = threadIdx.x & 63;
-    // packed fp16 arithmetic (the halvings are exact; one rounding per add): a quarter of the instructions of a float detour
-    const _Float16 hf = (_Float16)0.5f;
-    const half8 av = (a0 * hf + a1 * hf) + (l0 + l1) * hf;
-    *reinterpret_cast<half8 *>(p.avg + ((wg_w + (lane & 15) - p.w0 + p.avgw) * (int64_t)p.T + tt) * UP + 32 * wave + 8 * (lane >> 4)) = av;
-}
-
-// Gate math of two adjacent units of the split-operand kernels, written once with explicit fused multiply-adds so that
-// the one-tile and the two-tile kernel (batched records vs. single records of the 128-unit class) round identically:
-// a record must not change its calls with the way it was batched.
-__device__ __forceinline__ f32x2 split_gate(f32x2 ar, f32x2 ag, f32x2 az, f32x2 ax, f32x2 h, float zfold)
-{
-    const f32x2 rr = rcp1p_exp2_pair(ar.x, ar.y);
-    const f32x2 g = __builtin_elementwise_fma(rr, ag, ax);                      // x.W_h + b_in_h + r * (h.U_h + b_rec_h)
-    const f32x2 q = rcp1p_exp2_pair(g.x, g.y);
-    const f32x2 hh = __builtin_elementwise_fma(f32x2{ -2.0f, -2.0f }, q, f32x2{ 1.0f, 1.0f });   // tanh
-    const f32x2 z = rcp1p_exp2_pair(az.x - zfold, az.y - zfold);
-    return __builtin_elementwise_fma(z, h - hh, hh);                              // z*h + (1-z)*hh
-}
-
 // ---- split-operand variant (dgrp_model_set_precision(m, 1)) -------------------------------------------------------
 // Same decomposition, but both MFMA operands of the recurrent contraction carry fp32-grade precision as fp16 pairs:
 // U = U_hi + U_lo (packed once), h_{t-1} = h_hi + h_lo (two LDS tiles), and  U.h ~ U_hi.h_hi + U_hi.h_lo + U_lo.h_hi
@@ -662,7 +394,7 @@ __device__ __forceinline__ f32x2 split_gate(f32x2 ar, f32x2 ag, f32x2 az, f32x2 
 // every step through a small register ring in consumption order (k-step major, gates r, g, z); the hidden tile's two
 // fragments are read from LDS once per k-step.  Dense takes the lo tile too.  Written for correctness first: no staging of the softmax into
 // MFMA gaps, two reciprocals.  GRU up to 128 units (MODE 2 = the attention pre-pass).
-template <int NW, int MODE>
+template <int NW, int MODE, bool ONERCP>
 __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params pin)
 {
     gru_params p = pin;
@@ -696,9 +428,9 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
 
     const int r = lane & 31, wi_a = r & 15, dir = r >> 4, khalf = lane >> 5;
     const uint8_t *myseq = ctx.seqs + wi_a * p.Tp;
-    f32x2 h[8];
+    float h[16];                                              // gate state: h, or h - 1 (ONERCP), see split_gate_op
 #pragma unroll
-    for (int i = 0; i < 8; ++i) h[i] = f32x2{ 0.0f, 0.0f };
+    for (int i = 0; i < 16; ++i) h[i] = ONERCP ? -1.0f : 0.0f;
     _Float16 *hcur = ctx.hbuf, *hnxt = ctx.hbuf + 32 * HS, *lcur = lbuf, *lnxt = lbuf + 32 * HS;
     const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     const f32x4 zero4 = { 0, 0, 0, 0 };
@@ -775,20 +507,18 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
         if (t > 1) finish_step(t - 2);
         if (t > 0) dense_store(t - 1, dpl);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            h[i] = split_gate(f32x2{ ar[2 * i], ar[2 * i + 1] }, f32x2{ ag[2 * i], ag[2 * i + 1] }, f32x2{ az[2 * i], az[2 * i + 1] },
-                              f32x2{ ax[2 * i], ax[2 * i + 1] }, h[i], p.zfold);
+        for (int i = 0; i < 16; ++i) h[i] = split_gate_chain<ONERCP>(ar[i], ag[i], az[i], ax[i], h[i]);
         // publish h_t as an fp16 pair: hi = fp16(h), lo = fp16(h - hi)
         _Float16 *wrow = hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
         _Float16 *wlow = lnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-            const f32x2 h0 = h[2 * qd], h1 = h[2 * qd + 1];
-            const half4 hv = { (_Float16)h0.x, (_Float16)h0.y, (_Float16)h1.x, (_Float16)h1.y };
-            const half4 lv = { (_Float16)(h0.x - (float)hv.x), (_Float16)(h0.y - (float)hv.y), (_Float16)(h1.x - (float)hv.z),
-                               (_Float16)(h1.y - (float)hv.w) };
-            *reinterpret_cast<half4 *>(wrow + 8 * qd) = hv;
-            *reinterpret_cast<half4 *>(wlow + 8 * qd) = lv;
+            const float h4[4] = { split_state_h<ONERCP>(h[4 * qd]), split_state_h<ONERCP>(h[4 * qd + 1]), split_state_h<ONERCP>(h[4 * qd + 2]),
+                                  split_state_h<ONERCP>(h[4 * qd + 3]) };
+            uint2 hv, lv;
+            split_hi_lo4(h4, hv, lv);
+            *reinterpret_cast<uint2 *>(wrow + 8 * qd) = hv;
+            *reinterpret_cast<uint2 *>(wlow + 8 * qd) = lv;
         }
         __syncthreads();
         _Float16 *tmp = hcur; hcur = hnxt; hnxt = tmp;
@@ -1320,223 +1050,32 @@ static int launch_gru(const gru_params &p, int64_t groups, size_t lds, bool oner
     }
 }
 
-// ---- split operands, two row tiles per wave, everything resident (128-unit models, single-record launches) ----------
-// One wave per SIMD with the 512-register budget: U_hi AND U_lo of the wave's 32 units live in registers, so nothing
-// streams from L2, and the wave carries TWO row tiles (32 windows per workgroup).  The step is software-pipelined across
-// the tiles: while the matrix pipe works through one tile's 72 + 4 MFMAs the wave issues the other tile's gate math
-// between them (a wave issues in order; what sits between two MFMAs runs in their shadow).  LDS: each tile has the full
-// carve of a 16-window workgroup (`half_bytes` apart), so the shared helpers apply unchanged with workgroup index
-// 2 * blockIdx.x + tile.
-template <int MODE>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gru_split2_kernel(const gru_params pin, int half_bytes)
-{
-    constexpr int NW = 4, UP = 128, KS = 8, HS = UP + 8;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = pin.T, C = pin.C;
-    const uint4 *mypack = pin.pack + (size_t)wave * pin.nfrag * 64 + lane;
-    const uint4 *mylo = pin.pack_lo + (size_t)wave * 3 * KS * 64 + lane;
-    half8 Bz[KS + 1], Br[KS + 1], Bg[KS + 1], Lr[KS], Lg[KS], Lz[KS], Bxh, Bd_hi, Bd_lo;
-#pragma unroll
-    for (int k = 0; k <= KS; ++k) {
-        Bz[k] = __builtin_bit_cast(half8, mypack[(size_t)(k) * 64]);
-        Br[k] = __builtin_bit_cast(half8, mypack[(size_t)(KS + 1 + k) * 64]);
-        Bg[k] = __builtin_bit_cast(half8, mypack[(size_t)(2 * (KS + 1) + k) * 64]);
-    }
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {
-        Lr[k] = __builtin_bit_cast(half8, mylo[(size_t)(3 * k) * 64]);
-        Lg[k] = __builtin_bit_cast(half8, mylo[(size_t)(3 * k + 1) * 64]);
-        Lz[k] = __builtin_bit_cast(half8, mylo[(size_t)(3 * k + 2) * 64]);
-    }
-    Bxh = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1)) * 64]);
-    Bd_hi = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 1) * 64]);
-    Bd_lo = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 2) * 64]);
+// gru_split2.hip: the two-tile split-operand kernel of the 128-unit class
+int dgrp_split2_launch(const gru_params &p, int64_t groups, int half_bytes, bool onercp, hipStream_t stream);
 
-    struct tile_state {
-        gru_params p;                     // batched records: the two tiles may belong to different records
-        wg_ctx ctx;
-        _Float16 *hcur, *hnxt, *lcur, *lnxt;
-        const uint8_t *myseq;
-        f32x2 h[8];
-        f32x16 ar, ag, az, ax;            // pre-activations of the step in flight (ax: the candidate's input projection)
-        f32x4 dpl;
-    };
-    tile_state S0, S1;                      // two named objects, never indexed: they must stay in registers
-    const int r = lane & 31, wi_a = r & 15, dir = r >> 4, khalf = lane >> 5;
-    auto setup = [&](tile_state &X, int x) {
-        unsigned char *base = smem + (size_t)x * half_bytes;
-        _Float16 *lbuf = reinterpret_cast<_Float16 *>(base + pin.lo_tile_off);
-        for (int i = tid; i < 32 * HS; i += 256) lbuf[i] = (_Float16)0.0f;
-        X.p = pin;
-        const int64_t bid = wg_record_at<MODE>(pin, X.p, 2 * (int64_t)blockIdx.x + x);
-        X.ctx = wg_setup<NW, MODE>(X.p, base, bid);                                    // ends with a barrier
-        X.hcur = X.ctx.hbuf; X.hnxt = X.ctx.hbuf + 32 * HS;
-        X.lcur = lbuf; X.lnxt = lbuf + 32 * HS;
-        X.myseq = X.ctx.seqs + wi_a * pin.Tp;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) X.h[i] = f32x2{ 0.0f, 0.0f };
-    };
-    setup(S0, 0);
-    setup(S1, 1);
-    const f32x16 zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    const f32x4 zero4 = { 0, 0, 0, 0 };
-    const int cls = lane & 15;
-    const float fbias = cls < C ? pin.ffb[cls] : 0.0f;
-    const int doff = (lane & 15) * HS + 32 * wave + 8 * (lane >> 4);
-
-    auto finish_step = [&](const tile_state &X, int t) {
-        for (int reg = wave; reg < 4; reg += NW) {
-            const int wi = 4 * (lane >> 4) + reg;
-            finish_register<NW, MODE>(X.p, X.ctx, t, reg, fbias, X.ctx.rowoff[wi], X.ctx.row0s[wi]);
-        }
-    };
-    auto dense_issue = [&](const tile_state &X, const _Float16 *hb, const _Float16 *lb, int tt) -> f32x4 {
-        const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff), a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
-        const half8 l0 = *reinterpret_cast<const half8 *>(lb + doff), l1 = *reinterpret_cast<const half8 *>(lb + doff + 16 * HS);
-        if (MODE == 2 && (lane & 15) < X.ctx.nvalid)
-            split_avg_store(X.p, X.ctx.wg_w, tt, UP, wave, a0, a1, l0, l1);
-        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, Bd_hi, d, 0, 0, 0);
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, Bd_hi, d, 0, 0, 0);
-    };
-    auto dense_store = [&](const wg_ctx &ctx, int t, const f32x4 &d) {
-        float *dw = ctx.dpart + ((size_t)(t & 1) * 4 * NW + wave) * 64 + lane;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) dw[reg * NW * 64] = d[reg];
-    };
-    // gate math of elements 2i, 2i+1 of a tile whose pre-activations are complete
-    auto gate_piece = [&](tile_state &X, int i) {
-        X.h[i] = split_gate(f32x2{ X.ar[2 * i], X.ar[2 * i + 1] }, f32x2{ X.ag[2 * i], X.ag[2 * i + 1] },
-                            f32x2{ X.az[2 * i], X.az[2 * i + 1] }, f32x2{ X.ax[2 * i], X.ax[2 * i + 1] }, X.h[i], pin.zfold);
-    };
-    auto publish = [&](tile_state &X) {
-        _Float16 *wrow = X.hnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
-        _Float16 *wlow = X.lnxt + (lane & 31) * HS + 32 * wave + 4 * khalf;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const f32x2 h0 = X.h[2 * qd], h1 = X.h[2 * qd + 1];
-            const half4 hv = { (_Float16)h0.x, (_Float16)h0.y, (_Float16)h1.x, (_Float16)h1.y };
-            const half4 lv = { (_Float16)(h0.x - (float)hv.x), (_Float16)(h0.y - (float)hv.y), (_Float16)(h1.x - (float)hv.z),
-                               (_Float16)(h1.y - (float)hv.w) };
-            *reinterpret_cast<half4 *>(wrow + 8 * qd) = hv;
-            *reinterpret_cast<half4 *>(wlow + 8 * qd) = lv;
-        }
-        _Float16 *tmp = X.hcur; X.hcur = X.hnxt; X.hnxt = tmp;
-        tmp = X.lcur; X.lcur = X.lnxt; X.lnxt = tmp;
-    };
-    // the 76 MFMAs of tile X's step t; between the k-steps: the gate math of tile Y's step in flight (if any)
-    auto contract = [&](tile_state &X, int t, tile_state &Y, bool with_y) {
-        uint32_t b = X.myseq[dir ? T - 1 - t : t];
-        if (dir) b = b < 4 ? 3 - b : 4;
-        const uint32_t one = 0x3C00u << ((b & 1) * 16);
-        const uint32_t sel = b >> 1;
-        const uint4 xu = make_uint4(sel == 0 ? one : 0u, sel == 1 ? one : 0u, (sel == 2 ? one : 0u) | 0x3C000000u, 0u);
-        const half8 xa = __builtin_bit_cast(half8, xu);
-        const _Float16 *arow = X.hcur + r * HS + 8 * khalf, *lrow = X.lcur + r * HS + 8 * khalf;
-        X.ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[KS], xa, zero16, 0, 0, 0);
-        X.ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[KS], xa, zero16, 0, 0, 0);
-        X.az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[KS], xa, zero16, 0, 0, 0);
-        X.ax = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bxh, xa, zero16, 0, 0, 0);
-        // the fragments of k-step k+1 are requested before the MFMAs of k-step k: their LDS latency hides behind nine MFMAs
-        half8 hf = *reinterpret_cast<const half8 *>(arow), lf = *reinterpret_cast<const half8 *>(lrow);
-#pragma unroll
-        for (int k = 0; k < KS; ++k) {
-            half8 hfn = hf, lfn = lf;
-            if (k + 1 < KS) {
-                hfn = *reinterpret_cast<const half8 *>(arow + 16 * (k + 1));
-                lfn = *reinterpret_cast<const half8 *>(lrow + 16 * (k + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            X.ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], hf, X.ar, 0, 0, 0);
-            X.ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], hf, X.ag, 0, 0, 0);
-            X.az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[k], hf, X.az, 0, 0, 0);
-            X.ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], lf, X.ar, 0, 0, 0);
-            X.ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], lf, X.ag, 0, 0, 0);
-            X.az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[k], lf, X.az, 0, 0, 0);
-            X.ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Lr[k], hf, X.ar, 0, 0, 0);
-            X.ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Lg[k], hf, X.ag, 0, 0, 0);
-            X.az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Lz[k], hf, X.az, 0, 0, 0);
-            if (with_y) {
-                __builtin_amdgcn_sched_barrier(0);
-                gate_piece(Y, k);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            hf = hfn; lf = lfn;
-        }
-        X.dpl = zero4;
-        if (t > 0) X.dpl = dense_issue(X, X.hcur, X.lcur, t - 1);   // Dense(t-1) from the tile that is in LDS anyway
-    };
-
-    // prologue: tile 0, step 0
-    contract(S0, 0, S1, false);
-    for (int t = 0; t < T; ++t) {
-        // tile 1's step t  ||  tile 0's gate math of step t
-        contract(S1, t, S0, true);
-        if (t > 0) dense_store(S0.ctx, t - 1, S0.dpl);
-        publish(S0);
-        if (t > 1) finish_step(S0, t - 2);
-        __syncthreads();                                          // tile 0: h_t and the Dense(t-1) partials are in LDS
-        // tile 0's step t+1  ||  tile 1's gate math of step t
-        if (t + 1 < T) {
-            contract(S0, t + 1, S1, true);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) gate_piece(S1, i);
-        }
-        if (t > 0) dense_store(S1.ctx, t - 1, S1.dpl);
-        publish(S1);
-        if (t > 1) finish_step(S1, t - 2);
-        __syncthreads();
-    }
-    auto drain = [&](tile_state &X) {
-        const f32x4 dpl = dense_issue(X, X.hcur, X.lcur, T - 1);
-        if (T > 1) finish_step(X, T - 2);
-        dense_store(X.ctx, T - 1, dpl);
-        __syncthreads();
-        finish_step(X, T - 1);
-        if (MODE == 0 && pin.ospan > 0) flush_image<NW>(X.p, X.ctx);
-    };
-    drain(S0);
-    drain(S1);
-}
-
-template <int MODE>
-static int launch_split2(const gru_params &p, int64_t groups, int half_bytes, hipStream_t stream)
+template <int NW, bool ONERCP>
+static int launch_split_rcp(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
     static bool configured = false;
     if (!configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split2_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
-    hipLaunchKernelGGL((gru_split2_kernel<MODE>), dim3((unsigned)((groups + 1) / 2)), dim3(256), (size_t)2 * half_bytes, stream, p, half_bytes);
-    DGRP_LAUNCH_CHECK();
-    return DGRP_OK;
-}
-
-template <int NW>
-static int launch_split(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
-{
-    static bool configured = false;
-    if (!configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 0, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 1, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 2, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
     if (p.mode == 0)
-        hipLaunchKernelGGL((gru_split_kernel<NW, 0>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+        hipLaunchKernelGGL((gru_split_kernel<NW, 0, ONERCP>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     else if (p.mode == 1)
-        hipLaunchKernelGGL((gru_split_kernel<NW, 1>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+        hipLaunchKernelGGL((gru_split_kernel<NW, 1, ONERCP>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     else
-        hipLaunchKernelGGL((gru_split_kernel<NW, 2>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
+        hipLaunchKernelGGL((gru_split_kernel<NW, 2, ONERCP>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
+}
+template <int NW>
+static int launch_split(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
+{
+    return p.zfold != 0.0f ? launch_split_rcp<NW, true>(p, groups, lds, stream) : launch_split_rcp<NW, false>(p, groups, lds, stream);
 }
 
 // split-operand kernel selected (dgrp_model_set_precision) and applicable to this launch
@@ -1603,8 +1142,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
         const int half_bytes = (int)dgrp_align_up((int64_t)lds, 256);
         const bool one_tile = getenv("DGRP_SPLIT_ONE_TILE") != nullptr;      // A/B and tests: keep the one-tile kernel
         if (m->NW == 4 && 2 * half_bytes <= 160 * 1024 && groups >= 2 && !one_tile)
-            return mode == 0 ? launch_split2<0>(p, groups, half_bytes, stream)
-                 : mode == 1 ? launch_split2<1>(p, groups, half_bytes, stream) : launch_split2<2>(p, groups, half_bytes, stream);
+            return dgrp_split2_launch(p, groups, half_bytes, m->onercp != 0, stream);
         switch (m->NW) {
         case 1: return launch_split<1>(p, groups, lds, stream);
         case 2: return launch_split<2>(p, groups, lds, stream);
@@ -1678,7 +1216,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     if (split) {
         const int half_bytes = (int)dgrp_align_up((int64_t)lds, 256);
         if (m->NW == 4 && 2 * half_bytes <= 160 * 1024 && total_groups >= 2 && !getenv("DGRP_SPLIT_ONE_TILE"))
-            return mode == 0 ? launch_split2<0>(p, total_groups, half_bytes, stream) : launch_split2<2>(p, total_groups, half_bytes, stream);
+            return dgrp_split2_launch(p, total_groups, half_bytes, m->onercp != 0, stream);
         switch (m->NW) {
         case 1: return launch_split<1>(p, total_groups, lds, stream);
         case 2: return launch_split<2>(p, total_groups, lds, stream);
