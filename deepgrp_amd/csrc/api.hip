@@ -154,7 +154,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     m->KS = m->UP / 16;
     m->nfrag = 3 * (m->KS + 1) + 3;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
-    m->d_pack_lo = nullptr; m->precision = 0;
+    m->d_pack_lo = nullptr; m->precision = 0; m->d_pack16 = nullptr; m->d_xtab = nullptr;
     const int KS = m->KS, NF = m->nfrag, u3 = 3 * u;
     // The update z*h + (1-z)*tanh(g) can be written with ONE reciprocal, of (1 + 2^az)(1 + 2^ag), if that
     // product cannot overflow: |h| <= 1 and 0 < r < 1 bound both pre-activations by the weights' absolute
@@ -267,6 +267,45 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
             }
         CREATE_HIP(hipMalloc((void **)&m->d_pack_lo, lo.size() * 2));
         CREATE_HIP(hipMemcpy(m->d_pack_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+        if (m->NW == 4) {
+            // gru_split2_kernel's operands (gru_split2.hip).  A fragment of v_mfma_f32_16x16x32_f16: lane l, element j <-> A[row l & 15][k 8 (l >> 4) + j];
+            // here row = unit 32 w + 16 uh + (l & 15), k = recurrent row 32 ks + 8 (l >> 4) + j.  Same scaled values, same hi/lo split as above.
+            static const int order16[3] = { 1, 2, 0 };                                  // r, g, z in Keras column blocks [z | r | h]
+            std::vector<uint16_t> p16((size_t)4 * 48 * 64 * 8, 0);
+            for (int w = 0; w < 4; ++w)
+                for (int gi = 0; gi < 3; ++gi)
+                    for (int ks = 0; ks < 4; ++ks)
+                        for (int uh = 0; uh < 2; ++uh)
+                            for (int l = 0; l < 64; ++l)
+                                for (int j = 0; j < 8; ++j) {
+                                    const int g = order16[gi], unit = 32 * w + 16 * uh + (l & 15), k = 32 * ks + 8 * (l >> 4) + j;
+                                    uint16_t hi = 0, lo16 = 0;
+                                    if (unit < u && k < u) {
+                                        const float gs = g < 2 ? -1.4426950408889634f : 2.8853900817779268f;
+                                        const float x = gs * rec[(size_t)k * u3 + g * u + unit];
+                                        hi = f2h(x);
+                                        lo16 = f2h(x - h2f(hi));
+                                    }
+                                    const size_t f = (size_t)gi * 8 + ks * 2 + uh;
+                                    p16[(((size_t)w * 48 + f) * 64 + l) * 8 + j] = hi;
+                                    p16[(((size_t)w * 48 + 24 + f) * 64 + l) * 8 + j] = lo16;
+                                }
+            // input projection per base (one-hot input => a row lookup): kinds r, g (recurrent bias, inside r * (...)), z, x
+            std::vector<float> xt((size_t)5 * 4 * 128, 0.0f);
+            const double cs = -1.4426950408889634, ch = 2.8853900817779268;
+            for (int b = 0; b < 5; ++b)
+                for (int unit = 0; unit < u; ++unit) {
+                    float *row = &xt[(size_t)b * 512];
+                    row[0 * 128 + unit] = (float)(cs * ((double)kernel[(size_t)b * u3 + u + unit] + (double)bias[u + unit] + (double)bias[u3 + u + unit]));
+                    row[1 * 128 + unit] = (float)(ch * (double)bias[u3 + 2 * u + unit]);
+                    row[2 * 128 + unit] = (float)(cs * ((double)kernel[(size_t)b * u3 + unit] + (double)bias[unit] + (double)bias[u3 + unit]) + (m->onercp ? 1.0 : 0.0));
+                    row[3 * 128 + unit] = (float)(ch * ((double)kernel[(size_t)b * u3 + 2 * u + unit] + (double)bias[2 * u + unit]));
+                }
+            CREATE_HIP(hipMalloc((void **)&m->d_pack16, p16.size() * 2));
+            CREATE_HIP(hipMemcpy(m->d_pack16, p16.data(), p16.size() * 2, hipMemcpyHostToDevice));
+            CREATE_HIP(hipMalloc((void **)&m->d_xtab, xt.size() * 4));
+            CREATE_HIP(hipMemcpy(m->d_xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice));
+        }
         // Default for the models it covers: the split-operand kernel, the one that keeps every base within the 1e-3 of
         // the north star whatever the model's conditioning.  dgrp_model_set_precision(m, 0) or
         // DGRP_GRU_PRECISION=0 selects the 2.5x faster fp16-operand kernel.
@@ -297,7 +336,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     m->KS = m->UP / 16;
     m->nfrag = 4 * (m->KS + 1) + 2;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
-    m->d_pack_lo = nullptr; m->precision = 0;
+    m->d_pack_lo = nullptr; m->precision = 0; m->d_pack16 = nullptr; m->d_xtab = nullptr;
     const int KS = m->KS, NF = m->nfrag, u4 = 4 * u;
     std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
     frag_writer fw{ pack, NF };
@@ -342,6 +381,8 @@ DGRP_EXPORT int dgrp_model_destroy(dgrp_model *m)
     if (m->d_wtop) (void)hipFree(m->d_wtop);
     if (m->d_raw) (void)hipFree(m->d_raw);
     if (m->d_pack_lo) (void)hipFree(m->d_pack_lo);
+    if (m->d_pack16) (void)hipFree(m->d_pack16);
+    if (m->d_xtab) (void)hipFree(m->d_xtab);
     delete m;
     return DGRP_OK;
 }

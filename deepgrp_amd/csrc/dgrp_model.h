@@ -14,6 +14,11 @@ struct dgrp_model {
     int precision;    // 0: fused fp16-operand kernel; 1: split-operand kernel where it applies (dgrp_model_set_precision)
     uint4 *d_pack;    // [NW][nfrag][64] 8 x fp16 per lane
     uint4 *d_pack_lo; // GRU, NW <= 4: [NW][KS][3][64] lo halves of the recurrent fragments (k-step major, gates r, g, z), or NULL
+    // GRU, NW == 4 (97-128 units), for gru_split2_kernel (gru_split2.hip): the recurrent kernel as v_mfma_f32_16x16x32_f16 A fragments,
+    // [4 waves][(pass*3 + gate)*8 + kstep*2 + unit-half][64] with pass hi|lo, gates r, g, z, k-steps of 32, unit halves of 16;
+    // and the input projection as a table [5 bases][4 kinds r, g (recurrent bias only), z, x][128 units] fp32, exp2 domain
+    uint4 *d_pack16;
+    float *d_xtab;
     float *d_ffb;     // [16] dense bias, zero padded
     float *d_scale;   // [UP] attention scale (zero padded) or NULL
     float *d_wtop;    // [UP][16] rows of the dense kernel that multiply the context vector, or NULL

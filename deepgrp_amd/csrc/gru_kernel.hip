@@ -1098,6 +1098,27 @@ static int launch_lstm(const gru_params &p, int64_t groups, size_t lds, hipStrea
     return DGRP_OK;
 }
 
+// LDS carve of one row tile: fixed part, output image (mode 0: as many of the rows 16 windows span as `budget` bytes allow), and
+// behind them the lo halves of the hidden tile (split kernels).  Sets p.ospan and p.lo_tile_off, returns the tile's bytes.
+static size_t gru_tile_carve(const dgrp_model *m, gru_params &p, int mode, int64_t s, bool split, int pad, int64_t budget)
+{
+    const int lo_tiles = split ? gru_lds_hbuf(m->UP, pad) : 0;
+    const int fixed = gru_lds_hbuf(m->UP, pad) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
+    p.ospan = 0;
+    if (mode == 0) {
+        const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
+        const int64_t cap = (budget - fixed - lo_tiles) / (m->C * 4);
+        p.ospan = (int)(want < cap ? want : cap);
+        if (p.ospan < m->T) p.ospan = 0;
+    }
+    p.lo_tile_off = (int)dgrp_align_up(fixed + (int64_t)p.ospan * m->C * 4, 16);
+    return split ? (size_t)p.lo_tile_off + lo_tiles : (size_t)fixed + (size_t)p.ospan * m->C * 4;
+}
+// gru_split2_kernel (gru_split2.hip): two tile carves with row pitch UP + 16, then the input-projection table
+#define DGRP_SPLIT2_PAD 16
+#define DGRP_SPLIT2_XTAB_BYTES (5 * (4 * 128 * 4 + 32))
+static bool split2_applies(const dgrp_model *m) { return m->NW == 4 && m->d_pack16 && !getenv("DGRP_SPLIT_ONE_TILE"); }
+
 int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
                     int64_t w0, int64_t nw, int mode, float *d_out, void *d_avg, hipStream_t stream)
 {
@@ -1121,28 +1142,24 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     }
 #endif
     const bool split = use_split(m, mode);
-    const int lo_tiles = split ? gru_lds_hbuf(m->UP) : 0;           // the lo halves of the hidden tile, behind everything else
-    const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
-    p.ospan = 0;
-    if (mode == 0) {
-        // rows spanned by 16 consecutive windows, capped so that two workgroups fit a CU's 160 KiB
-        const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
-        const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed - lo_tiles) / (m->C * 4);   // NW > 4: one workgroup per CU anyway
-        p.ospan = (int)(want < cap ? want : cap);
-        if (p.ospan < m->T) p.ospan = 0;
-    }
     p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
-    p.lo_tile_off = (int)dgrp_align_up(fixed + (int64_t)p.ospan * m->C * 4, 16);
-    const size_t lds = split ? (size_t)p.lo_tile_off + lo_tiles : (size_t)fixed + (size_t)p.ospan * m->C * 4;
-    DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T, fixed);
+    p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0;
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
-    if (split) {
-        // 128-unit class: two row tiles per wave, all fragments resident (no L2 stream) when two carves fit the CU's LDS
-        const int half_bytes = (int)dgrp_align_up((int64_t)lds, 256);
-        const bool one_tile = getenv("DGRP_SPLIT_ONE_TILE") != nullptr;      // A/B and tests: keep the one-tile kernel
-        if (m->NW == 4 && 2 * half_bytes <= 160 * 1024 && groups >= 2 && !one_tile)
+    if (split && split2_applies(m)) {
+        // 128-unit class: two row tiles per workgroup, everything resident, whenever two carves and the table fit the CU's LDS
+        // (a property of the model's window size, not of the record: a record never changes kernels with the way it is batched)
+        const int half_bytes = (int)dgrp_align_up((int64_t)gru_tile_carve(m, p, mode, s, true, DGRP_SPLIT2_PAD, 74 * 1024), 256);
+        if (2 * half_bytes + DGRP_SPLIT2_XTAB_BYTES <= 160 * 1024) {
+            p.xtab_off = 2 * half_bytes;
             return dgrp_split2_launch(p, groups, half_bytes, m->onercp != 0, stream);
+        }
+    }
+    // rows spanned by 16 consecutive windows, capped so that two workgroups fit a CU's 160 KiB (NW > 4: one workgroup per CU anyway)
+    const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, (m->NW > 4 ? 144 : 72) * 1024);
+    DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T,
+                 gru_lds_seq(p.Tp));
+    if (split) {
         switch (m->NW) {
         case 1: return launch_split<1>(p, groups, lds, stream);
         case 2: return launch_split<2>(p, groups, lds, stream);
@@ -1202,21 +1219,20 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     p.stamps = nullptr;
     p.recs = (const gru_rec *)d_recs; p.wg_first = d_wg_first; p.nrec = nrec; p.avgw = 0;
     const bool split = use_split(m, mode);
-    const int lo_tiles = split ? gru_lds_hbuf(m->UP) : 0;
-    const int fixed = gru_lds_hbuf(m->UP) + gru_lds_dpart(m->NW) + gru_lds_seq(p.Tp) + gru_lds_meta();
-    const int64_t want = (DGRP_WG_WINDOWS - 1) * s + m->T;
-    const int64_t cap = ((m->NW > 4 ? 144 : 72) * 1024 - fixed - lo_tiles) / (m->C * 4);
-    p.ospan = mode == 0 ? (int)(want < cap ? want : cap) : 0;
-    if (p.ospan < m->T) p.ospan = 0;
     p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
-    p.lo_tile_off = (int)dgrp_align_up(fixed + (int64_t)p.ospan * m->C * 4, 16);
-    const size_t lds = split ? (size_t)p.lo_tile_off + lo_tiles : (size_t)fixed + (size_t)p.ospan * m->C * 4;
-    DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T, fixed);
+    p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0;
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
-    if (split) {
-        const int half_bytes = (int)dgrp_align_up((int64_t)lds, 256);
-        if (m->NW == 4 && 2 * half_bytes <= 160 * 1024 && total_groups >= 2 && !getenv("DGRP_SPLIT_ONE_TILE"))
+    if (split && split2_applies(m)) {
+        const int half_bytes = (int)dgrp_align_up((int64_t)gru_tile_carve(m, p, mode, s, true, DGRP_SPLIT2_PAD, 74 * 1024), 256);
+        if (2 * half_bytes + DGRP_SPLIT2_XTAB_BYTES <= 160 * 1024) {
+            p.xtab_off = 2 * half_bytes;
             return dgrp_split2_launch(p, total_groups, half_bytes, m->onercp != 0, stream);
+        }
+    }
+    const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, (m->NW > 4 ? 144 : 72) * 1024);
+    DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T,
+                 gru_lds_seq(p.Tp));
+    if (split) {
         switch (m->NW) {
         case 1: return launch_split<1>(p, total_groups, lds, stream);
         case 2: return launch_split<2>(p, total_groups, lds, stream);

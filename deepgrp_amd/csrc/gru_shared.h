@@ -41,6 +41,10 @@ struct gru_params {
     const uint4 *pack_lo;
     int lo_tile_off;
     float zfold;
+    // gru_split2_kernel only: 16x16x32 A fragments and the input-projection table (dgrp_model.h), byte offset of the table's LDS copy
+    const uint4 *pack16;
+    const float *xtab;
+    int xtab_off;
 };
 
 // The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
@@ -104,7 +108,7 @@ __device__ __forceinline__ void global_atomic_max(unsigned *p, unsigned v)
 }
 
 // LDS carve (bytes) -- shared by host and device
-__host__ __device__ static inline int gru_lds_hbuf(int UP) { return 2 * 32 * (UP + 8) * 2; }
+__host__ __device__ static inline int gru_lds_hbuf(int UP, int pad = 8) { return 2 * 32 * (UP + pad) * 2; }   // pad: row pitch UP + pad halves
 __host__ __device__ static inline int gru_lds_dpart(int NW) { return 2 * NW * 64 * 16; }
 __host__ __device__ static inline int gru_lds_seq(int Tp) { return DGRP_WG_WINDOWS * Tp; }
 __host__ __device__ static inline int gru_lds_meta() { return DGRP_WG_WINDOWS * 8 + DGRP_WG_WINDOWS * 4; }
@@ -146,14 +150,14 @@ template <int MODE>
 __device__ __forceinline__ int64_t wg_record(const gru_params &pin, gru_params &p) { return wg_record_at<MODE>(pin, p, blockIdx.x); }
 
 // carve, stage the windows' sequences, zero the state and the image, work out the placement (ends with a barrier)
-template <int NW, int MODE>
+template <int NW, int MODE, int HPAD = 8>
 __device__ __forceinline__ wg_ctx wg_setup(const gru_params &p, unsigned char *smem, int64_t bid)
 {
-    constexpr int UP = 32 * NW, HS = UP + 8;
+    constexpr int UP = 32 * NW, HS = UP + HPAD;
     wg_ctx c;
     c.hbuf = reinterpret_cast<_Float16 *>(smem);
-    c.dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP));
-    c.seqs = smem + gru_lds_hbuf(UP) + gru_lds_dpart(NW);
+    c.dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP, HPAD));
+    c.seqs = smem + gru_lds_hbuf(UP, HPAD) + gru_lds_dpart(NW);
     c.row0s = reinterpret_cast<int64_t *>(c.seqs + gru_lds_seq(p.Tp));
     c.rowoff = reinterpret_cast<int *>(c.row0s + DGRP_WG_WINDOWS);
     c.obuf = reinterpret_cast<unsigned *>(c.rowoff + DGRP_WG_WINDOWS);

@@ -200,11 +200,13 @@ def test_cli_precise(tmp_path, orc):
 
 @pytest.mark.parametrize("u", [97, 128])
 def test_two_tile_and_one_tile_split_kernels_agree(dev, orc, u, monkeypatch):
-    """The 128-unit class runs `gru_split2_kernel` (two row tiles per wave, 32 windows per workgroup) on single-record
-    launches and `gru_split_kernel` on batched ones; DGRP_SPLIT_ONE_TILE keeps the latter everywhere.  Window counts
-    around the 16 / 32 boundaries exercise the empty second tile and the partial last workgroup; both forms must agree
-    with each other BIT FOR BIT (a record's calls must not depend on how it was batched: tools/fuzz_cli.py found a tie
-    that flipped when they rounded differently) and with the float64 statement."""
+    """The 128-unit class runs `gru_split2_kernel` (two row tiles per workgroup, 16x16x32 MFMAs, input projection from an LDS
+    table) whenever two tile carves fit the CU's LDS -- a property of the model's window size and step, never of the record or
+    of the way records are batched, so a record cannot change kernels between runs -- and `gru_split_kernel` otherwise;
+    DGRP_SPLIT_ONE_TILE forces the latter.  Both run the same gate chain and the same three-pass split, but not the same
+    summation order (MFMA shape) nor the same input projection (fp32 table row vs hi+lo MFMA), so they agree to fp32
+    rounding, not bit for bit: held to 2e-6 of each other and 1e-5 of the float64 statement.  Window counts around the
+    16 / 32 boundaries exercise the empty second tile and the partial last workgroup."""
     from deepgrp_amd.pipeline import ContigPipeline, DeviceModel
     rng = np.random.default_rng(u)
     T, s = 40, 7
@@ -219,14 +221,14 @@ def test_two_tile_and_one_tile_split_kernels_agree(dev, orc, u, monkeypatch):
         one = dm.forward_windows(d, s, 0, nw).cpu().numpy()
         monkeypatch.delenv("DGRP_SPLIT_ONE_TILE")
         want = orc.nn_forward(idx, w, s, 0, nw, np.float64)
-        assert np.array_equal(two, one) and np.abs(two - want).max() < 1e-5, nw
+        assert np.abs(two - one).max() < 2e-6 and np.abs(two - want).max() < 1e-5 and np.abs(one - want).max() < 1e-5, nw
         # merged output (MODE 0) incl. the reference's batch placement, against the one-tile form
         pipe = ContigPipeline(dm, s, 4, 50, 50, True)
         m2 = pipe.merged(d).cpu().numpy()
         monkeypatch.setenv("DGRP_SPLIT_ONE_TILE", "1")
         m1 = pipe.merged(d).cpu().numpy()
         monkeypatch.delenv("DGRP_SPLIT_ONE_TILE")
-        assert np.array_equal(m2, m1), nw
+        assert np.abs(m2 - m1).max() < 2e-6 and np.array_equal(m2 == 0, m1 == 0), nw      # same placement, fp32-grade values
     dm.close()
 
 

@@ -1,27 +1,31 @@
 #!/usr/bin/env python3
 """Generate deepgrp_amd/csrc/gru_split2_phase.inc: the instruction order of one phase of gru_split2_kernel.
 
-A phase = the 82 MFMAs of tile X's step (4 input-projection + 8 k-steps x 9 + 6 Dense) with tile Y's epilogue cut into
-single operations that sit in the gaps between them (gru_split2.hip explains why).  The macros are defined there:
+A phase = the 150 MFMAs (v_mfma_f32_16x16x32_f16) of tile X's step -- 4 k-steps of 32 x 36 (3 passes x 3 gates x 2 unit
+halves x 2 row halves) + 6 Dense -- with tile Y's epilogue cut into single operations that sit in the gaps between them
+(gru_split2.hip explains why).  The macros are defined there:
 
-    M_IN(i) M_K(k, j) M_D(i)   X's MFMAs (asm volatile: stay in program order)
-    PF(k) RDD                  X's LDS reads: fragments of k-step k, Dense operands
-    XP(op)                     Y: one-hot operand of its next step (0: read the base, 1: build the operand)
+    M_K(ks, n) M_D(i)          X's MFMAs (asm volatile: stay in program order)
+    PF(ks) RDD                 X's LDS reads: fragments of k-step ks, Dense operands
+    AXL(sub)                   Y: the candidate's input projection (table row) of sub-tile sub
     DS(i)                      Y: store Dense partial i of the previous step
     G(e, op)                   Y: link `op` (0..11) of element e's gate chain (split_gate_op)
-    PB(g, op)                  Y: publish group g (elements 4g..4g+3): 0 state -> h, 1 hi = fp16(h), 2 h - hi, 3 lo = fp16(h - hi), 4 two LDS stores
+    PB(g, op)                  Y: publish sub-tile g (elements 4g..4g+3): 0 state -> h, 1 hi = fp16(h), 2 h - hi, 3 lo = fp16(h - hi), 4 two LDS stores
+    XP(op)                     Y: bases of its next step (0: read the two bytes, 1: table row offsets)
     BAR                        s_waitcnt lgkmcnt(0) + s_barrier, flip Y's ping-pong
-    RD0                        Y: first fragments of its next step
+    RD0 CI(g, sub)             Y's next step: first fragments; accumulator sub of gate g starts as its table row
     FN(op)                     Y: softmax + max-merge of the previous step's logits (0..12)
     GAP                        sched_barrier(0)
+    ST(i)                      diagnostic build only (-DDGRP_STAMP): add the cycles since the last stamp to section i
 
 Cost model (cycles of the SIMD's issue port, MI355X_MICROARCH.md "vector-instruction ISSUE cost"): transcendental 8, plain
-VALU 4; an MFMA 32x32x16 occupies the pipe for 32 cycles and the port for 8, so up to BUDGET = 24 cycles of other work per
-gap are hidden; a 16x16x32 gap hides 8.  Operations are taken from two queues (before / after the barrier) in order and
-packed greedily; nothing that reads the previous phase's accumulators goes into the first FREE_HEAD gaps (MFMA result ->
-VALU read needs wait states the compiler does not pad behind inline asm).
+VALU 4, LDS instruction 4.  A 16x16x32 MFMA occupies the pipe for 16 cycles and the port for 8; the epilogue's ~1500 port
+cycles do not fit the 150 x 8 free ones, so the stream is paced by the port and the aim is an even spread: BUDGET cycles of
+work per gap, taken in order from the queue in front of the barrier and the one behind it.  Nothing that reads the previous
+phase's accumulators or Dense result goes into the first FREE_HEAD gaps (MFMA result -> VALU read needs wait states the
+compiler does not pad behind inline asm).
 
-    python tools/gen_split2_schedule.py [--skew 3] [--bar-k 6] [--budget 24] [--report]
+    python tools/gen_split2_schedule.py [--skew 3] [--bar 104] [--budget 12] [--report]
 """
 import argparse
 import os
@@ -32,7 +36,7 @@ GATE_T = {0, 1, 3, 5, 10}            # transcendental links of the ONERCP chain 
 
 def gate_pipeline(skew):
     """Gate chains of the 16 elements, element e lagging e*skew links behind element 0 (independent chains interleave);
-    a group of four elements is published as soon as its last chain is done."""
+    a sub-tile of four elements is published as soon as its last chain is done."""
     ops, done = [], set()
     tau = 0
     while len(done) < 16:
@@ -44,7 +48,7 @@ def gate_pipeline(skew):
                     done.add(e)
                     if e % 4 == 3:
                         g = e // 4
-                        ops += [(f"PB({g}, 0)", 16), (f"PB({g}, 1)", 8), (f"PB({g}, 2)", 16), (f"PB({g}, 3)", 8), (f"PB({g}, 4)", 12)]
+                        ops += [(f"PB({g}, 0)", 16), (f"PB({g}, 1)", 8), (f"PB({g}, 2)", 16), (f"PB({g}, 3)", 8), (f"PB({g}, 4)", 8)]
         tau += 1
     return ops
 
@@ -52,58 +56,81 @@ def gate_pipeline(skew):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skew", type=int, default=3)
-    ap.add_argument("--bar-k", type=int, default=6, help="the barrier follows the last MFMA of this k-step")
-    ap.add_argument("--budget", type=int, default=24)
-    ap.add_argument("--dense-budget", type=int, default=8)
-    ap.add_argument("--free-head", type=int, default=2)
+    ap.add_argument("--bar", type=int, default=112, help="the barrier follows this many of the 144 recurrent MFMAs")
+    ap.add_argument("--budget", type=float, default=0, help="port cycles per gap in front of the barrier (0 = the queue's average)")
+    ap.add_argument("--post-budget", type=float, default=0)
+    ap.add_argument("--free-head", type=int, default=4)
+    ap.add_argument("--xp1", type=int, default=12, help="gap that turns Y's next bases into table offsets (the bytes are read in gap 0)")
     ap.add_argument("--report", action="store_true")
     ap.add_argument("-o", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "deepgrp_amd", "csrc",
                                                "gru_split2_phase.inc"))
     a = ap.parse_args()
 
-    slots = [(f"M_IN({i})", a.budget, ("in", i)) for i in range(4)]
-    for k in range(8):
-        slots += [(f"M_K({k}, {j})", a.budget, ("k", k, j)) for j in range(9)]
-    slots += [(f"M_D({i})", a.dense_budget, ("d", i)) for i in range(6)]
-    bar_slot = 4 + 9 * (a.bar_k + 1) - 1                           # index of the slot the barrier closes
-
-    pre = [(f"DS({i})", 6) for i in range(4)] + gate_pipeline(a.skew)
-    post = [("RD0", 8), ("RDD", 16), ("FN(0)", 16), ("FN(1)", 16)] + [(f"FN({i})", 8) for i in range(2, 6)] + [("FN(6)", 16)] + \
+    slots = []                                                     # (macro, key)
+    for ks in range(4):
+        for n in range(36):
+            slots.append((f"M_K({ks}, {n})", ("k", ks, n)))
+            if n % 12 == 11 and 3 * ks + n // 12 in (1, 3, 5, 7, 9, 10):      # one link of the Dense chain every other pass
+                slots.append((f"M_D({[1, 3, 5, 7, 9, 10].index(3 * ks + n // 12)})", ("d",)))
+    nrec = 0
+    bar_slot = None
+    for i, (_, key) in enumerate(slots):
+        if key[0] == "k":
+            nrec += 1
+            if nrec == a.bar:
+                bar_slot = i
+    # queue in front of the barrier: Dense partials out, the gate pipeline; behind it: Y's next step, then softmax/merge
+    pre = [(f"DS({i})", 4) for i in range(4)] + gate_pipeline(a.skew)
+    post = [("RD0", 16)] + [(f"CI({g}, {sub})", 4) for g in range(3) for sub in range(4)] + \
+           [("FN(0)", 8), ("-", 0), ("-", 0), ("-", 0), ("FN(1)", 16)] + [(f"FN({i})", 8) for i in range(2, 6)] + [("FN(6)", 16)] + \
            [(f"FN({i})", 8) for i in range(7, 11)] + [("FN(11)", 12), ("FN(12)", 16)]
-    pinned = {0: [("XP(0)", 4)], 1: [("XP(1)", 40)]}
-    for k in range(7):                                             # fragments of k-step k+1: early in k-step k
-        pinned.setdefault(4 + 9 * k + 1, []).append((f"PF({k + 1})", 8))
+    pinned = {0: [("XP(0)", 8), ("RDD", 16)], 1: [("AXL(0)", 4), ("AXL(1)", 4)], 2: [("AXL(2)", 4), ("AXL(3)", 4)], a.xp1: [("XP(1)", 24)]}
+    for ks in range(3):                                            # fragments of k-step ks+1: early in k-step ks
+        si = next(i for i, s in enumerate(slots) if s[1] == ("k", ks, 2))
+        pinned.setdefault(si, []).append((f"PF({ks + 1})", 16))
 
+    # even spread: each queue is paid out at its own average rate (its cost / its gaps, --budget / --post-budget if given)
+    npre = bar_slot + 1 - a.free_head
+    npost = len(slots) - bar_slot - 1
+    rate_pre = a.budget or sum(c for _, c in pre) / npre
+    rate_post = a.post_budget or min(12.0, max(8.0, sum(c for _, c in post) / max(1, npost - 8)))
     lines, rep = [], []
     over = 0
-    for si, (mf, budget, _) in enumerate(slots):
+    credit = 0.0
+    for si, (mf, _) in enumerate(slots):
         items, used = [], 0
         for name, c in pinned.get(si, []):
             items.append(name); used += c
-        queue = pre if si <= bar_slot else post
+        queue, rate = (pre, rate_pre) if si <= bar_slot else (post, rate_post)
+        if si == bar_slot + 1:
+            credit = 0.0
         if si >= a.free_head:
-            while queue and (used + queue[0][1] <= budget or used == 0 or (si == bar_slot and queue is pre)):
+            credit += rate
+            while queue and (queue[0][1] <= credit + 2 or (si == bar_slot and queue is pre)):
                 name, c = queue.pop(0)
-                items.append(name); used += c
+                if name == "-":                                    # filler: what follows waits for the next gap
+                    credit = min(credit, 0.0)
+                    break
+                items.append(name); used += c; credit -= c
+        if si == 0:
+            items.insert(0, "ST(2)")
         if si == bar_slot:
-            items.append("BAR")
-        over += max(0, used - budget)
+            items += ["ST(0)", "BAR", "ST(1)"]
+        over += max(0, used - 8)
         lines.append(f"{mf} " + " ".join(items) + (" " if items else "") + "GAP")
-        rep.append((mf, used, budget, items))
-    if pre or post:
-        # whatever is left goes behind the last MFMA (exposed)
-        rest = [n for n, _ in pre + post]
-        over += sum(c for _, c in pre + post)
-        lines.append(" ".join(rest) + " GAP")
+        rep.append((mf, used, items))
+    left = [n for n, _ in pre + post if n != "-"]
+    if left:                                                       # whatever is left goes behind the last MFMA (exposed)
+        lines.append(" ".join(left) + " GAP")
     hdr = ["// generated by tools/gen_split2_schedule.py " + " ".join(f"--{k.replace('_', '-')} {v}" for k, v in sorted(vars(a).items())
                                                                      if k not in ("report", "o")),
-           f"// {len(slots)} MFMA gaps; issue-port cycles beyond the gaps' budgets: {over}"]
+           f"// {len(slots)} MFMA gaps; modelled issue-port cycles beyond the 8 free ones of each gap: {over}"]
     with open(a.o, "w") as fh:
         fh.write("\n".join(hdr + lines) + "\n")
     if a.report:
-        for mf, used, budget, items in rep:
-            print(f"{mf:12s} {used:3d}/{budget:2d}  {' '.join(items)}")
-    print(f"wrote {os.path.relpath(a.o)}: over-budget cycles {over}, left over: {len(pre) + len(post)} ops")
+        for mf, used, items in rep:
+            print(f"{mf:12s} {used:3d}  {' '.join(items)}")
+    print(f"wrote {os.path.relpath(a.o)}: port cycles beyond the gaps {over}, behind the last MFMA: {len(left)} ops")
 
 
 if __name__ == "__main__":

@@ -15,6 +15,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "lstm":
     FL = 16 * u * u * 200 + 2 * u * 5 * 200
 else:
     w = synthetic.trained_weights()
+    if os.environ.get("GRU_ONLY_ZERO"):           # power probe: same instruction stream on all-zero operands (DVFS give-back)
+        w = {k: (np.zeros_like(v) if isinstance(v, np.ndarray) else v) for k, v in w.items()}
     m = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, 200)
     FL = 12 * 128 * 128 * 200 + 2 * 128 * 5 * 200
 st, d_idx = upload_sequence(synthetic.synthetic_chromosome(int(mbp * 1e6)))
