@@ -3,45 +3,73 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mbp M]
 
-A "step" is one pass of the whole hot path (class-index encode -> GRU + dense + softmax +
-max-merge -> score transform -> MSS + vote -> segment extraction -> record gather) over one
-synthetic chromosome per GPU whose bytes are already resident in HBM.  N > 1 is launched by
-torchrun, one rank per GPU; records shard by contig (weak scaling, no data-path collective),
-the only exchange is the gather of segment records to rank 0 over RCCL.
+Workload: one synthetic chromosome of M Mbp per GPU, default 250 (BASELINE configs[2], the size the north-star target is
+quoted on; `--mbp 50` = configs[1]).  A "step" is one pass of the whole hot path over it -- class-index encode -> GRU +
+dense + softmax + max-merge -> score transform -> MSS + vote -> segment extraction -> record gather -- through the
+package's default entry point (`dgrp_predict_record`, the call the command line makes per record), with the sequence
+bytes already resident in HBM.  N > 1: one rank per GPU (`python bench.py --gpus N` starts torch.distributed.run itself
+when it was not started by it), records shard by contig (weak scaling, no data-path collective), the only exchange is
+the gather of segment records to rank 0 over RCCL.
 
-Prints ONE JSON line (rank 0) carrying `roofline` for the dominant kernel (the fused GRU
-kernel, MFMA-bound, timed live with HIP events on its stream) and `cpu_baseline` (the CPU
-restatement of the same path, oracle/, timed on this host on a bounded sample).
-
-The timed path is the package's default for this model: the split-operand GRU kernel, whose class probabilities agree
-with an fp32 evaluation to ~1e-6 on every base (`accuracy`).  `--fast` times the fp16-operand kernel instead (2.5x
-faster; within 1e-3 of fp32 on 99.98 % of the bases of this workload, not on all); without the flag that mode is
-measured after the timed region and reported as `fast_mode`, for information.
+Prints ONE JSON line (rank 0):
+  value / ms_per_step   the device-resident step above, K steps between barriers, max over ranks
+  roofline              the recurrent kernel (MFMA-bound): algorithmic flop of a launch / its duration, from HIP events the
+                        library records around the launch on its stream INSIDE the timed steps (dgrp_kernel_timer_*)
+  stages                per-stage milliseconds of one step (a separate, staged pass over the same input)
+  e2e                   the same record from FASTA bytes in host memory (a file in /dev/shm) to TSV bytes in host memory:
+                        device ingest (A1) + upload over PCIe + the step + TSV text (A12), as the command line runs it
+  accuracy              the timed kernel against the plain-fp32 kernels on windows spread over the chromosome
+  fast_mode             for information: the fp16-operand kernel (`--fast`) on the same input, and its accuracy
+  cpu_baseline          the CPU restatement of the same path (oracle/, all host threads) on a bounded sample
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from deepgrp_amd import synthetic                                  # noqa: E402
-from deepgrp_amd.distributed import gather_records                 # noqa: E402
-from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence   # noqa: E402
 
 T, STEP, UNITS, CLASSES, BATCH, MIN_MSS, XDROP = 200, 50, 128, 5, 256, 50, 50
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md, chip-level parameters
 FLOP_PER_WINDOW = 12 * UNITS * UNITS * T + 2 * UNITS * CLASSES * T      # SURVEY 8(d)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mbp", type=float, default=250.0, help="chromosome size per GPU in Mbp (250 = configs[2], 50 = configs[1])")
+    ap.add_argument("--weights", choices=("trained", "random"), default="trained",
+                    help="trained: deepgrp_amd/data/synthetic_gru128.npz (fitted to the planted repeats, genome-like output); "
+                         "random: Keras initialisers scaled by --gain (stationary noise, the MSS worst case)")
+    ap.add_argument("--gain", type=float, default=3.0, help="weight scale of the random model")
+    ap.add_argument("--cpu-sample-bp", type=int, default=400_000)
+    ap.add_argument("--fast", action="store_true", help="time the fp16-operand GRU kernel instead of the default split-operand one")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed steps: no stages / e2e / other-mode / accuracy legs")
+    ap.add_argument("--accuracy-windows", type=int, default=4096, help="windows compared with the fp32 yardstick after the run (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py starts the ranks itself")
+    return ap.parse_args()
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as fresh child processes (nothing in this process has
+    touched the GPU yet) and pass their output through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(weights, sample_bp: int):
     """The oracle (CPU restatement, all host threads) on a bounded sample of the same workload."""
+    import numpy as np
+    from deepgrp_amd import synthetic
     from oracle import oracle as orc
     seq = synthetic.synthetic_chromosome(sample_bp, contig=0, flank=1000).decode()
     w = orc.Weights(weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
@@ -61,29 +89,24 @@ def cpu_baseline(weights, sample_bp: int):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mbp", type=float, default=50.0, help="chromosome size per GPU in Mbp (configs[1] = 50)")
-    ap.add_argument("--weights", choices=("trained", "random"), default="trained",
-                    help="trained: deepgrp_amd/data/synthetic_gru128.npz (fitted to the planted repeats, genome-like output); "
-                         "random: Keras initialisers scaled by --gain (stationary noise, the MSS worst case)")
-    ap.add_argument("--gain", type=float, default=3.0, help="weight scale of the random model")
-    ap.add_argument("--cpu-sample-bp", type=int, default=400_000)
-    ap.add_argument("--fast", action="store_true", help="time the fp16-operand GRU kernel instead of the default split-operand one")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--accuracy-windows", type=int, default=4096, help="windows compared with the fp32 yardstick after the run (0 = skip)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
-    args = ap.parse_args()
-
+    args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args))                                # before any GPU call in this process
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from deepgrp_amd import synthetic
+    from deepgrp_amd._lib import check, lib
+    from deepgrp_amd.distributed import gather_records
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, stream_ptr, upload_sequence
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
     ndev = torch.cuda.device_count()
     if local_rank >= ndev and args.backend == "nccl":
         sys.exit(f"rank {rank}: local rank {local_rank} but only {ndev} GPUs visible")
@@ -112,12 +135,11 @@ def main():
     # the resident input of a step: the stripped sequence bytes in HBM
     d_seq = torch.from_numpy(np.frombuffer(raw, np.uint8)[startpos:startpos + d_idx.numel()].copy()).to(dev)
     n = d_seq.numel()
-    from deepgrp_amd._lib import check, lib
-    from deepgrp_amd.pipeline import stream_ptr
+    L = lib()
 
-    def step():
-        check(lib().dgrp_encode(d_seq.data_ptr(), n, d_idx.data_ptr(), stream_ptr()), "dgrp_encode")
-        rows = pipe.run_idx(d_idx, startpos, contig=rank)
+    def step(p=pipe):
+        check(L.dgrp_encode(d_seq.data_ptr(), n, d_idx.data_ptr(), stream_ptr()), "dgrp_encode")
+        rows = p.run_idx(d_idx, startpos, contig=rank)     # dgrp_predict_record: the package's default path
         return gather_records(rows, dev)
 
     def fence():
@@ -125,58 +147,127 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def kernel_timer_read():
+        ms, launches, windows = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        check(L.dgrp_kernel_timer_read(C.byref(ms), C.byref(launches), C.byref(windows)), "dgrp_kernel_timer_read")
+        return ms.value, launches.value, windows.value
+
     for _ in range(args.warmup):
         step()
     fence()
-    pipe.event_log = []
+    check(L.dgrp_kernel_timer_enable(1), "dgrp_kernel_timer_enable")      # HIP events around the recurrent kernel, on its stream
     t0 = time.perf_counter()
     nrows = 0
     for _ in range(args.steps):
         nrows = len(step())
     fence()
     dt = time.perf_counter() - t0
+    kern_ms, kern_launches, kern_windows = kernel_timer_read()
+    check(L.dgrp_kernel_timer_enable(0), "dgrp_kernel_timer_enable")
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    main_log = pipe.event_log
-    # for information: the other fused kernel of this model on the same input, same step function, outside the timed region
-    other = None
-    if rank == 0 and model.supports_split:
-        pipe_o = ContigPipeline(model, STEP, BATCH, MIN_MSS, XDROP, use_mss=True, fast=not args.fast)
-        step_o = lambda: (check(lib().dgrp_encode(d_seq.data_ptr(), n, d_idx.data_ptr(), stream_ptr()), "dgrp_encode"),
-                          pipe_o.run_idx(d_idx, startpos, contig=rank))[1]
-        step_o()
-        torch.cuda.synchronize()
-        pipe_o.event_log = []
-        t1 = time.perf_counter()
-        for _ in range(max(1, min(args.steps, 3))):
-            rows_o = step_o()
-        torch.cuda.synchronize()
-        dt_o = (time.perf_counter() - t1) / max(1, min(args.steps, 3))
-        other = {"value": round(n_bases / dt_o / 1e6, 3), "unit": "Mbp/s (1 GPU, this rank)", "ms_per_step": round(dt_o * 1e3, 3),
-                 "kernel_ms": round(float(np.mean([a.elapsed_time(b) for a, b, _ in pipe_o.event_log])), 3), "rows_out": int(len(rows_o))}
-    # dominant kernel: the fused GRU kernel (one launch per dgrp_forward_merge for this model)
-    pipe.event_log = main_log
-    kern_ms = [a.elapsed_time(b) for a, b, _ in pipe.event_log]
-    kern_windows = [w for _, _, w in pipe.event_log]
-    avg_ms = float(np.mean(kern_ms))
-    achieved = float(np.mean(kern_windows)) * FLOP_PER_WINDOW / (avg_ms * 1e-3) / 1e12
+    avg_ms = kern_ms / max(kern_launches, 1)
+    win_per_launch = kern_windows / max(kern_launches, 1)
+    achieved = win_per_launch * FLOP_PER_WINDOW / (avg_ms * 1e-3) / 1e12
 
-    # HBM traffic of that kernel from the PMC passes of profiles/ (separate rocprofv3 --pmc runs of this
-    # command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this launch size
+    extras = rank == 0 and not args.no_extras
+    stages = e2e = other = None
+    if extras:
+        # ---- per-stage milliseconds of one step: the staged form of the same path, a stage at a time
+        def staged():
+            out = {}
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            check(L.dgrp_encode(d_seq.data_ptr(), n, d_idx.data_ptr(), stream_ptr()), "dgrp_encode")
+            torch.cuda.synchronize(); out["encode"] = time.perf_counter() - t; t = time.perf_counter()
+            merged = pipe.merged(d_idx)
+            torch.cuda.synchronize(); out["forward_merge"] = time.perf_counter() - t; t = time.perf_counter()
+            labels = pipe.labels(merged)
+            torch.cuda.synchronize(); out["scores_mss_vote"] = time.perf_counter() - t; t = time.perf_counter()
+            del merged
+            rows = pipe.segments(labels, startpos, rank)
+            out["segments_and_readback"] = time.perf_counter() - t
+            return out, len(rows)
+        staged()
+        reps = [staged() for _ in range(2)]
+        assert all(r[1] == nrows for r in reps), "staged path and dgrp_predict_record disagree on the row count"
+        stages = {k: round(float(np.mean([r[0][k] for r in reps])) * 1e3, 3) for k in reps[0][0]}
+
+        # ---- end to end: FASTA bytes in host memory -> TSV bytes in host memory, as the command line runs a file
+        from deepgrp_amd.fasta import read_multi_fasta_device
+        from deepgrp_amd.runner import RecordRunner, rows_text, rows_text_batch
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+        fa_path = os.path.join(shm, f"dgrp_bench_{os.getpid()}.fa")
+        body = np.frombuffer(raw, np.uint8)
+        full = body.size // 60 * 60
+        lines = np.empty((full // 60, 61), np.uint8)
+        lines[:, :60] = body[:full].reshape(-1, 60)
+        lines[:, 60] = 10
+        try:
+            with open(fa_path, "wb") as fh:
+                fh.write(b">chr_bench\n")
+                fh.write(lines.tobytes())
+                if body.size > full:
+                    fh.write(body[full:].tobytes() + b"\n")
+            del lines
+            fasta_bytes = os.path.getsize(fa_path)
+
+            def file_to_tsv():
+                runner = RecordRunner(pipe)
+                parts = []
+                for kind, key, rows in runner.results(read_multi_fasta_device(fa_path)):
+                    parts.append(rows_text_batch(fa_path, key, rows) if kind == "batch" else rows_text(fa_path, key, rows))
+                return "".join(parts).encode()
+            file_to_tsv()
+            ts = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                tsv = file_to_tsv()
+                ts.append(time.perf_counter() - t)
+            e2e = {"value": round(n_bases / float(np.mean(ts)) / 1e6, 3), "unit": "Mbp/s (1 GPU, this rank)",
+                   "ms": round(float(np.mean(ts)) * 1e3, 3), "fasta_bytes": int(fasta_bytes), "tsv_bytes": len(tsv),
+                   "rows_out": tsv.count(b"\n"),
+                   "what": "FASTA file in host memory (60-column lines) -> device ingest (A1) incl. upload over PCIe -> the step -> TSV "
+                           "text in host memory (A12); model already loaded"}
+        finally:
+            if os.path.exists(fa_path):
+                os.unlink(fa_path)
+
+        # ---- for information: the other fused kernel of this model on the same input, same step function
+        if model.supports_split:
+            pipe_o = ContigPipeline(model, STEP, BATCH, MIN_MSS, XDROP, use_mss=True, fast=not args.fast)
+            step(pipe_o)
+            torch.cuda.synchronize()
+            check(L.dgrp_kernel_timer_enable(1), "dgrp_kernel_timer_enable")
+            t1 = time.perf_counter()
+            k_o = max(1, min(args.steps, 3))
+            for _ in range(k_o):
+                rows_o = step(pipe_o)
+            torch.cuda.synchronize()
+            dt_o = (time.perf_counter() - t1) / k_o
+            ms_o, launches_o, _w = kernel_timer_read()
+            check(L.dgrp_kernel_timer_enable(0), "dgrp_kernel_timer_enable")
+            other = {"value": round(n_bases / dt_o / 1e6, 3), "unit": "Mbp/s (1 GPU, this rank)", "ms_per_step": round(dt_o * 1e3, 3),
+                     "kernel_ms": round(ms_o / max(launches_o, 1), 3), "rows_out": int(len(rows_o))}
+
+    # HBM traffic of the timed kernel from the PMC passes of profiles/ (separate rocprofv3 --pmc runs of this command;
+    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this launch size
     fused_name = "gru_fused_kernel<4, 0, %s>" % ("true" if model.kernel_flags & 1 else "false")
-    split_name = "gru_split2_kernel<0>"          # 128-unit class, single-record launch: two row tiles per wave (gru_kernel.hip)
+    split_name = "gru_split2_kernel<0, %s>" % ("true" if model.kernel_flags & 1 else "false")
     kernel_name = fused_name if not pipe.split else split_name
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_gru_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_gru_traffic.json")
     if os.path.exists(tpath) and args.weights == "trained":
         with open(tpath) as fh:
             per_kernel = json.load(fh).get("kernels", {}).get(kernel_name.split("<")[0])
         if per_kernel:
-            traffic = round(per_kernel["hbm_bytes_per_window"] * float(np.mean(kern_windows)))
+            traffic = round(per_kernel["hbm_bytes_per_window"] * win_per_launch)
     if rank == 0:
         value = n_bases * world * args.steps / dt / 1e6
+        cfg = "configs[2]" if abs(args.mbp - 250) < 1e-9 else "configs[1]" if abs(args.mbp - 50) < 1e-9 else "custom size"
         out = {
             "metric": "Mbp/sec predicted (whole node) at window=200 stride=50, 5-class",
             "value": round(value, 3), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,15 +277,22 @@ def main():
                              "GRU: weights and hidden state as f16 hi+lo pairs on the MFMA (three passes, the 2^-22 cross term dropped), "
                              "f32 accumulate and state: pre-activations to fp32 rounding") + "; post-processing f32/f64/int exactly as the reference",
             "data": "synthetic",
-            "config": {"workload": f"{args.mbp:g} Mbp synthetic chromosome per GPU (BASELINE configs[1]), "
+            "config": {"workload": f"{args.mbp:g} Mbp synthetic chromosome per GPU (BASELINE {cfg}), "
                                    f"window={T} stride={STEP} hidden={UNITS} {CLASSES}-class, batch_size={BATCH}, "
-                                   f"MSS min_len={MIN_MSS} xdrop={XDROP}, {wdesc}",
+                                   f"MSS min_len={MIN_MSS} xdrop={XDROP}, {wdesc}; a step = dgrp_encode + dgrp_predict_record + record "
+                                   f"gather on HBM-resident sequence bytes (FASTA ingest, upload and TSV text: see e2e)",
                        "rows_out": int(nrows), "parallelism": f"contig-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": kernel_name, "flop_per_window": FLOP_PER_WINDOW, "avg_launch_ms": round(avg_ms, 3),
-                         "windows_per_launch": int(np.mean(kern_windows)), "launches_timed": len(kern_ms)},
+                         "windows_per_launch": int(win_per_launch), "launches_timed": int(kern_launches),
+                         "timing": "HIP events recorded by the library around each launch on its stream inside the timed steps (dgrp_kernel_timer_*)"},
         }
+        if stages is not None:
+            out["stages"] = dict(unit="ms per step (staged pass, one stage at a time, host clock around a device sync)", **stages)
+        if e2e is not None:
+            out["e2e"] = e2e
+
         # how far each fused kernel is from a plain-fp32 evaluation of the same model on the device (ref_kernels.hip), on
         # windows spread over this rank's chromosome; outside the timed region
         def acc_obj(acc):
@@ -202,7 +300,7 @@ def main():
                     "q99_window_max_abs_dp": round(acc["q99_window_max"], 8), "max_abs_dp": round(acc["max_abs_diff"], 8),
                     "frac_positions_above_1e-3": round(acc["positions_above_1e-3"] / acc["positions_checked"], 7),
                     "argmax_flips": acc["argmax_flips"], "positions": acc["positions_checked"]}
-        if args.accuracy_windows > 0:
+        if args.accuracy_windows > 0 and not args.no_extras:
             out["accuracy"] = dict(yardstick="plain-fp32 HIP kernels (dgrp_forward_windows_reference), themselves within 2e-5 of the float64 CPU statement",
                                    kernel=kernel_name, **acc_obj(model.check_accuracy(d_idx, STEP, args.accuracy_windows, level=1 if pipe.split else 0)))
         if other is not None:

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "dgrp_predict_batch": (cint, [vp, vp, i64, vp, vp, vp, vp, i64, i64, cint, cint, vp, i64, C.POINTER(i64), vp, i64, vp]),
     "dgrp_confusion_matrix": (cint, [vp, vp, i64, cint, vp, vp, vp]),
     "dgrp_filter_segments": (cint, [vp, vp, i64, i64, vp]),
+    "dgrp_kernel_timer_enable": (cint, [cint]),
+    "dgrp_kernel_timer_read": (cint, [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]),
 }
 
 _lib = None

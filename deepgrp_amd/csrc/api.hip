@@ -38,6 +38,54 @@ DGRP_EXPORT int dgrp_device_info(char *name, size_t name_cap, int *cu_count, int
     return DGRP_OK;
 }
 
+// ---- kernel timer (include/deepgrp_hip.h, "instrumentation") --------------------------------------------------------
+struct timed_launch { hipEvent_t start, stop; int64_t windows; };
+static thread_local bool g_timer_on = false;
+static thread_local std::vector<timed_launch> g_timed;
+
+dgrp_timer_scope::dgrp_timer_scope(hipStream_t s, int64_t nw) : stream(s), windows(nw), start(nullptr), on(g_timer_on)
+{
+    if (!on) return;
+    if (hipEventCreate(&start) != hipSuccess || hipEventRecord(start, stream) != hipSuccess) on = false;
+}
+dgrp_timer_scope::~dgrp_timer_scope()
+{
+    if (!on) return;
+    hipEvent_t stop = nullptr;
+    if (hipEventCreate(&stop) == hipSuccess && hipEventRecord(stop, stream) == hipSuccess) g_timed.push_back({ start, stop, windows });
+}
+
+static void timer_clear()
+{
+    for (auto &t : g_timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    g_timed.clear();
+}
+
+DGRP_EXPORT int dgrp_kernel_timer_enable(int on)
+{
+    timer_clear();
+    g_timer_on = on != 0;
+    return DGRP_OK;
+}
+
+DGRP_EXPORT int dgrp_kernel_timer_read(double *h_ms, int64_t *h_launches, int64_t *h_windows)
+{
+    double ms = 0.0;
+    int64_t windows = 0;
+    for (auto &t : g_timed) {
+        DGRP_HIP(hipEventSynchronize(t.stop));
+        float one = 0.0f;
+        DGRP_HIP(hipEventElapsedTime(&one, t.start, t.stop));
+        ms += one;
+        windows += t.windows;
+    }
+    if (h_ms) *h_ms = ms;
+    if (h_launches) *h_launches = (int64_t)g_timed.size();
+    if (h_windows) *h_windows = windows;
+    timer_clear();
+    return DGRP_OK;
+}
+
 // deepgrp/sequence.pyx:27-30
 DGRP_EXPORT int dgrp_strip_n(const uint8_t *h_seq, int64_t len, int64_t *startpos, int64_t *kept)
 {

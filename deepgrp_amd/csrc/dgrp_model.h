@@ -27,6 +27,16 @@ struct dgrp_model {
     int64_t raw_kernel, raw_rec, raw_bias, raw_ffk, raw_ffb, raw_scale;
 };
 
+// dgrp_kernel_timer_* (api.hip): brackets a recurrent-kernel launch with HIP events while the calling thread has the timer enabled
+struct dgrp_timer_scope {
+    hipStream_t stream;
+    int64_t windows;
+    hipEvent_t start;
+    bool on;
+    dgrp_timer_scope(hipStream_t s, int64_t nw);
+    ~dgrp_timer_scope();
+};
+
 // rows of LDS the fused kernel may use to pre-merge a workgroup's windows
 int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
                     int64_t w0, int64_t nw, int mode, float *d_out, void *d_avg, hipStream_t stream);

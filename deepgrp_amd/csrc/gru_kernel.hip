@@ -1123,6 +1123,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
                     int64_t w0, int64_t nw, int mode, float *d_out, void *d_avg, hipStream_t stream)
 {
     if (nw <= 0) return DGRP_OK;
+    dgrp_timer_scope timed(stream, nw);                             // bench.py: HIP events around the launch (no-op unless enabled)
     gru_params p;
     p.idx = d_idx; p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
     p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = (_Float16 *)d_avg;
@@ -1210,6 +1211,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
                           int64_t nrec, int64_t total_groups, int mode, float *d_out, void *d_avg, hipStream_t stream)
 {
     if (nrec <= 0 || total_groups <= 0) return DGRP_OK;
+    dgrp_timer_scope timed(stream, total_groups * DGRP_WG_WINDOWS);
     DGRP_REQUIRE(m->NW <= 8 && (mode == 0 || (mode == 2 && m->cell == 0)), "dgrp_gru_launch_batch: mode 0, or the GRU attention pre-pass");
     gru_params p;
     p.idx = d_idx; p.n = 0; p.s = s; p.w0 = 0; p.nw = 0; p.place = dgrp_placement{ 0, 0 };

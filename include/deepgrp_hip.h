@@ -115,10 +115,14 @@ int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int *attention)
  * prove (1 + 2^az)(1 + 2^ag) finite in float32; otherwise (or with DGRP_GRU_SAFE=1 in the environment at
  * construction) the two-reciprocal form.  Negative on a NULL model. */
 int dgrp_model_flags(const dgrp_model *m);
-/* (addition) Precision of the recurrent contraction for every later call on this model: 0 = fp16 MFMA operands (default,
- * the benchmarked path); 1 = split operands: weights and hidden state as fp16 hi+lo pairs, three MFMA passes, fp32-grade
- * pre-activations (GRU, <= 128 units -- with attention it is the recurrent pre-pass that runs split, avg[t] still crosses to the second
- * kernel as fp16; DGRP_EINVAL for LSTM and larger models).  dgrp_model_flags bit 1 reports it. */
+/* (addition) Precision of the recurrent contraction for every later call on this model:
+ * 1 = split operands, the DEFAULT wherever such a kernel exists (GRU up to 128 units): weights and hidden state enter the matrix
+ * cores as fp16 hi+lo pairs, three MFMA passes, fp32-grade pre-activations (with attention it is the recurrent pre-pass that runs
+ * split; avg[t] crosses to the second kernel as fp16); 0 = fp16 MFMA operands, the default of the other models (LSTM, GRU beyond
+ * 128 units), ~2x faster, class probabilities within 1e-3 of fp32 except on ill-conditioned windows.  DGRP_EINVAL for level 1 on a
+ * model without a split kernel.  dgrp_model_flags bit 1 reports the level.  The level is a property of the HANDLE, read by every
+ * call at launch time: host threads may share a handle as long as none of them changes the level while another has calls in
+ * flight (set it once, before sharing; the package's pool of record threads uses one level per pipeline). */
 int dgrp_model_set_precision(dgrp_model *m, int level);
 
 /* ---- A4: model.predict_on_batch (deepgrp/prediction.py:106)
@@ -234,6 +238,14 @@ int dgrp_confusion_matrix(const int8_t *d_true, const int8_t *d_pred, int64_t n,
 /* deepgrp.prediction.filter_segments (deepgrp/prediction.py:244-260): runs of one positive label shorter than
  * min_len become 0.  d_out may be d_labels (the reference works in place). */
 int dgrp_filter_segments(const int8_t *d_labels, int8_t *d_out, int64_t n, int64_t min_len, void *stream);
+
+/* ---- instrumentation (bench.py's roofline figure; no counterpart in the reference, no effect on results).
+ * While enabled for the CALLING HOST THREAD, every launch of a recurrent forward kernel (GRU / LSTM, fused or split) that this
+ * thread makes through any entry point above is bracketed by two HIP events on the launch's stream.  dgrp_kernel_timer_read waits
+ * for the recorded events, returns the summed device time in milliseconds, the number of launches and the windows they covered,
+ * and forgets them; enabling again also starts from an empty list. */
+int dgrp_kernel_timer_enable(int on);
+int dgrp_kernel_timer_read(double *h_ms, int64_t *h_launches, int64_t *h_windows);
 
 #ifdef __cplusplus
 }

@@ -63,18 +63,20 @@ def test_20mbp_postprocessing_exact(orc, trained):
     np.testing.assert_array_equal(_rows3(rows), orc.segments(lab, st))
 
 
-def test_50mbp_properties(trained):
-    """configs[1] size: properties that hold for any input."""
+def _size_independent_properties(trained, n_bases, contig, other_chunk):
+    """Properties that hold for any input, at any size; returns what the size-specific checks go on with."""
     T, s, C = 200, 50, 5
-    raw = synthetic.synthetic_chromosome(50_000_000, contig=0)
+    raw = synthetic.synthetic_chromosome(n_bases, contig=contig)
     st, d_idx = upload_sequence(raw)
+    del raw
     n = d_idx.numel()
-    assert st == 10_000 and n == 50_000_000 - 20_000
+    assert st == 10_000 and n == n_bases - 20_000
     pipe = ContigPipeline(trained)
     merged = pipe.merged(d_idx)
     # chunking the windows differently must not change a bit (max is order independent)
-    merged2 = ContigPipeline(trained, chunk_windows=77_776).merged(d_idx)
+    merged2 = ContigPipeline(trained, chunk_windows=other_chunk).merged(d_idx)
     assert torch.equal(merged, merged2)
+    del merged2
     nwin = len(range(0, n - T, s))
     covered = (nwin // 256 * 256 - 1) * s + T                  # full batches sit where they belong
     assert float(merged[:covered].max(dim=1).values.min()) >= 1.0 / C - 1e-6       # a softmax row's max
@@ -103,3 +105,45 @@ def test_50mbp_properties(trained):
     cls = merged.argmax(dim=1)
     changed = labels.long() != cls
     assert bool((cls[changed] == 0).all())
+    return pipe, st, d_idx, merged, rows
+
+
+def test_50mbp_properties(trained):
+    """configs[1] size."""
+    _size_independent_properties(trained, 50_000_000, 0, 77_776)
+
+
+def test_250mbp_properties_and_far_offsets(trained):
+    """configs[2]: the 250 Mbp chromosome the north-star target is quoted on (a 1.25 G-element merged array: the place a
+    32-bit index would slip).  The property set of the 50 Mbp case, the one-call path (dgrp_predict_record, what the
+    command line and bench.py run) against the staged one, and -- since no CPU statement covers this size -- windows
+    and merged rows at the FAR end of the record against the plain-fp32 kernels: window probabilities of the last 4 096
+    windows within 1e-5 (fp32-grade) of the yardstick, and the merged rows they cover (incl. the reference's
+    partial-last-batch placement) bit-identical to a max-merge of those same probabilities done here."""
+    T, s, C, B = 200, 50, 5, 256
+    pipe, st, d_idx, merged, rows = _size_independent_properties(trained, 250_000_000, 2, 300_016)
+    n = d_idx.numel()
+    one_call = pipe.run_idx(d_idx, st)
+    np.testing.assert_array_equal(_rows3(one_call), _rows3(rows))
+    assert len(rows) > 50_000
+    nwin = len(range(0, n - T, s))
+    nw = 4096
+    w0 = nwin - nw
+    got = trained.forward_windows(d_idx, s, w0, nw)
+    ref = trained.forward_windows_reference(d_idx, s, w0, nw)
+    assert float((got - ref).abs().max()) < 1e-5
+    # placement at far offsets (SURVEY Q2): full-batch windows sit at w * s, the short last batch (r windows) at
+    # (nfull * r + (w - nfull * B)) * s -- for this record in the middle of the array
+    nfull, r = nwin // B, nwin % B
+    assert r > 0 and nfull * B > w0
+    # rows reached by NO window outside [w0, nfull * B): a max-merge of `got` done here must equal the array bit for bit
+    row_a, row_b = w0 * s + T, nfull * B * s
+    want = torch.zeros((row_b - w0 * s + T, C), dtype=torch.float32, device=merged.device)
+    for w in range(w0, nfull * B):
+        a = (w - w0) * s
+        want[a:a + T] = torch.maximum(want[a:a + T], got[w - w0])
+    assert torch.equal(merged[row_a:row_b], want[T:T + row_b - row_a])
+    # the short batch: every one of its windows is dominated by the array at its (shifted) rows
+    for w in range(nfull * B, nwin):
+        a = (nfull * r + (w - nfull * B)) * s
+        assert bool((merged[a:a + T] >= got[w - w0]).all())
