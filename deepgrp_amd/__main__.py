@@ -93,7 +93,8 @@ class CommandLineParser:
         predict = subparsers.add_parser(name="predict", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
                                         description="predict using a deepgrp model")
         predict.add_argument("model", type=str, help="Keras model in HDF5 format")
-        predict.add_argument("FASTA", nargs="+", type=str, help="Fasta input files ('-' = stdin)")
+        predict.add_argument("FASTA", nargs="+", type=str, help="Fasta input files ('-' = stdin); a `<fasta>.gz.npz` written by "
+                                                                "`preprocess_sequence` is accepted too (one record per file)")
         predict.add_argument("--output", type=str, default="-", help="Output filename")
         predict.add_argument("--no_use_mss", "-m", action="store_true", help="Disable maximum scoring segment algorithm")
         verify = subparsers.add_parser(name="verify", formatter_class=argparse.ArgumentDefaultsHelpFormatter,
@@ -182,12 +183,32 @@ class CommandLineParser:
         _LOG.info("Forward kernel: %s", "plain fp32 kernels (--precise)" if pipe.fp32 else
                   "fused, split operands (fp32-grade)" if pipe.split else "fused, fp16 operands")
         if pipe.fp32 and getattr(args, "split_contigs", False):
-            sys.exit("--precise is not combined with --split_contigs for this model")
+            sys.exit("--precise is not combined with --split_contigs for this model")      # same verdict on every rank, before any collective
         outstream = None
         if rank == 0:
             outstream = sys.stdout if args.output == "-" else open(args.output, "w")
 
         def records_of(filename):
+            if filename.endswith(".npz") and os.path.isfile(filename):
+                # (addition) the one-hot `<fasta>.gz.npz` that `preprocess_sequence` writes for training
+                # (deepgrp/_scripts/preprocess_sequence.py:71-78), as an alternative input: ONE record, named after the file
+                # (the format keeps no header); same stripping of leading/trailing N as one_hot_encode_dna_sequence
+                from .preprocessing import load_onehot_npz
+                fwd = load_onehot_npz(filename)
+                if fwd.size and not (np.isin(fwd, (0, 1)).all() and (fwd.sum(axis=0) == 1).all()):
+                    raise ValueError(f"{filename}: `fwd` is not one-hot")
+                idx = fwd.argmax(axis=0).astype(np.uint8)
+                header = os.path.basename(filename)[:-len(".npz")]
+                keep = np.flatnonzero(idx != 4)
+                if idx.size == 0:
+                    return
+                if keep.size == 0:
+                    yield header, DeviceRecord(int(idx.size), None, -int(idx.size))        # all N: the reference raises (sequence.pyx:32)
+                    return
+                st, en = int(keep[0]), int(keep[-1]) + 1
+                d_idx = torch.from_numpy(np.ascontiguousarray(idx[st:en])).to(torch.device("cuda", torch.cuda.current_device()))
+                yield header, DeviceRecord(st, d_idx, en - st)
+                return
             if filename == "-" or not os.path.isfile(filename):
                 filestream = sys.stdin if filename == "-" else open(filename, "r")
                 try:
@@ -213,8 +234,9 @@ class CommandLineParser:
                     for header, rec in records_of(filename):
                         records.append((filename, header, rec))
                 length = lambda r: r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
+                from .distributed import raise_together, run_split
                 if getattr(args, "split_contigs", False):
-                    from .distributed import merged_split
+                    # every record over all ranks (distributed.run_split); errors are per record and hit every rank alike
                     parts = []
                     for i, (_f, _h, rec) in enumerate(records):
                         if isinstance(rec, DeviceRecord):
@@ -223,17 +245,19 @@ class CommandLineParser:
                             startpos, d_idx = rec.startpos, rec.d_idx
                         else:
                             startpos, d_idx = upload_sequence(rec.encode("utf-8"))
-                        merged = merged_split(pipe, d_idx)
-                        if rank == 0:
-                            parts.append(pipe.segments(pipe.labels(merged), startpos, i))
+                        parts.append(run_split(pipe, d_idx, startpos, i))
                     allrows = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
                 else:
                     mine = shard_contigs([length(r[2]) for r in records], world)[rank]
                     # this rank's share through the same pool / batching as the single-process path, keyed by record index
-                    parts = []
-                    for kind, key, rows in runner.results((i, records[i][2]) for i in mine):
-                        rows["contig"] = np.asarray(key, np.int32)[rows["contig"]] if kind == "batch" else key
-                        parts.append(rows)
+                    parts, failure = [], None
+                    try:
+                        for kind, key, rows in runner.results((i, records[i][2]) for i in mine):
+                            rows["contig"] = np.asarray(key, np.int32)[rows["contig"]] if kind == "batch" else key
+                            parts.append(rows)
+                    except Exception as e:                  # noqa: BLE001 -- re-raised on every rank together, below
+                        failure = e
+                    raise_together(failure)                 # a record that raises (all-N ...) must not leave the others in the gather
                     local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
                     allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
                 if rank == 0:

@@ -94,45 +94,150 @@ def placement_rows(a: int, b: int, nwin: int, batch: int, step: int, T: int):
     return min(rows), max(rows) + T
 
 
-def merged_split(pipe, d_idx: torch.Tensor) -> torch.Tensor:
-    """The max-merged probability array [N, C] of ONE record computed by all ranks together: every
-    rank runs the fused GRU kernel on its share of the windows into a buffer that covers just its rows,
-    rank 0 gathers the slices and max-combines them (neighbouring shares overlap by T - step rows; max
-    is exact, so the result is bit-identical to a single-GPU run).  Returned on rank 0 (None elsewhere).
-    The sequential post-processing (scores, MSS, segments: ~3 % of the time) then runs on rank 0."""
+def _forward_rows(pipe, d_idx: torch.Tensor, w0: int, nw: int, lo: int, hi: int) -> torch.Tensor:
+    """Max-merge of windows [w0, w0 + nw) into a zeroed buffer that stands for rows [lo, hi) of the record's [N, C] array
+    (the kernels index rows absolutely: they are handed the address row 0 would have).  Any model: attention models get
+    their avg[t] workspace here, chunked like ContigPipeline.merged does."""
+    from ._lib import check, lib
+    from .pipeline import stream_ptr
+    L, m = lib(), pipe.model
+    n, C_ = d_idx.numel(), m.classes
+    out = torch.zeros((max(hi - lo, 1), C_), dtype=torch.float32, device=d_idx.device)
+    if nw <= 0:
+        return out
+    m.set_precision(1 if getattr(pipe, "split", False) else 0)
+    base = out.data_ptr() - lo * C_ * 4
+    chunk = int(getattr(pipe, "chunk_windows", 1 << 20))
+    if m.attention:
+        per = m.vecsize * (((m.units + 31) // 32) * 32 * 2 + m.classes * 4)
+        chunk = max(16, min(chunk, (2 << 30) // per // 16 * 16))
+    work = None
+    w = w0
+    while w < w0 + nw:
+        k = min(chunk, w0 + nw - w)
+        wb = L.dgrp_forward_workspace_bytes(m.handle, k)
+        if work is None or work.numel() < wb:
+            work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
+        check(L.dgrp_forward_merge(m.handle, d_idx.data_ptr(), n, pipe.step, pipe.batch, w, k, base, work.data_ptr(), work.numel(),
+                                   stream_ptr()), "dgrp_forward_merge")
+        w += k
+    return out
+
+
+def split_plan(n: int, T: int, step: int, batch: int, world: int):
+    """Who computes and who owns what when ONE record is spread over `world` ranks (same answer on every rank).
+    The full batches' windows [0, first_short) are shared contiguously (16-window units); rank k OWNS the rows from its first
+    window's row to the next rank's (the last rank to n), and its windows spill at most T - step rows into the ranges behind it.
+    The short last batch (< batch windows) is placed elsewhere by the reference: every rank computes it itself.
+    Returns (nwin, first_short, shares [(a, b)], owned [(lo, hi)], short rows (lo, hi))."""
+    nwin = len(range(0, n - T, step))
+    nfull, r = divmod(nwin, batch)
+    first_short = nfull * batch
+    shares = [window_share(first_short, world, k) for k in range(world)]
+    starts = [a * step for a, _b in shares]
+    owned = [(0 if k == 0 else starts[k], n if k == world - 1 else starts[k + 1]) for k in range(world)]
+    short = (nfull * r * step, min((nfull * r + r - 1) * step + T, n)) if r else (0, 0)
+    return nwin, first_short, shares, owned, short
+
+
+def run_split(pipe, d_idx: torch.Tensor, startpos: int, contig: int = 0) -> np.ndarray:
+    """Segment records of ONE record computed by all ranks together (SURVEY 8e last row / 8f N1); returned on rank 0.
+
+    1. every rank runs the forward kernels on its share of the windows into a buffer over the rows it owns plus the
+       T - step rows its last windows spill behind them, and on the short last batch (a few windows, placed by Q2);
+    2. the spill rows go to the ranks that own them (point to point; max-combining is exact, so the merged rows are
+       bit-identical to a single-GPU run) -- (T - step) * C * 4 bytes per rank boundary;
+    3. every rank turns its rows into MSS scores and classes (A7); these travel to rank 0 as float32 + int8 = 5 bytes per base
+       (the reference's float64 score is a widened float32, prediction.py:53-57) -- instead of 20 bytes of probabilities;
+    4. rank 0 runs the sequential part (MSS scan + vote, segments: ~1 % of the time) and returns the rows.
+    `-m` (no MSS) gathers the merged rows themselves: its softmax subtracts the record's global maximum."""
     from ._lib import check, lib
     from .pipeline import stream_ptr
     L, m = lib(), pipe.model
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = d_idx.device
-    n, C_ = d_idx.numel(), m.classes
-    nwin = L.dgrp_window_count(n, m.vecsize, pipe.step)
-    a, b = window_share(nwin, world, rank)
-    lo, hi = placement_rows(a, b, nwin, pipe.batch, pipe.step, m.vecsize)
-    local = torch.zeros((max(hi - lo, 1), C_), dtype=torch.float32, device=dev)
-    if b > a:
-        if m.attention:
-            raise NotImplementedError("splitting one record over GPUs is implemented for models without attention")
-        m.set_precision(1 if getattr(pipe, "split", False) else 0)
-        # absolute row indexing: hand the kernel the address row 0 would have
-        base = local.data_ptr() - lo * C_ * 4
-        check(L.dgrp_forward_merge(m.handle, d_idx.data_ptr(), n, pipe.step, pipe.batch, a, b - a, base, None, 0, stream_ptr()),
-              "dgrp_forward_merge")
+    n, C_, T = d_idx.numel(), m.classes, m.vecsize
     cpu = dist.get_backend() == "gloo"
     cdev = torch.device("cpu") if cpu else dev
-    span = torch.tensor([lo, hi], dtype=torch.int64, device=cdev)
-    spans = [torch.zeros_like(span) for _ in range(world)]
-    dist.all_gather(spans, span)
-    spans = [(int(s[0]), int(s[1])) for s in spans]
-    cap = max(max(h - l for l, h in spans), 1)
-    send = torch.zeros((cap, C_), dtype=torch.float32, device=cdev)
-    send[: hi - lo] = local[: hi - lo].to(cdev)
-    parts = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-    dist.gather(send, parts, dst=0)
-    if rank != 0:
-        return None
-    out = torch.zeros((n, C_), dtype=torch.float32, device=dev)
-    for (l, h), part in zip(spans, parts):
-        if h > l:
-            torch.maximum(out[l:h], part[: h - l].to(dev), out=out[l:h])
-    return out
+    nwin, first_short, shares, owned, short = split_plan(n, T, pipe.step, pipe.batch, world)
+    a, b = shares[rank]
+    own_lo, own_hi = owned[rank]
+    spill_hi = min((b - 1) * pipe.step + T, n) if b > a else own_hi
+    hi = max(own_hi, spill_hi)
+    local = _forward_rows(pipe, d_idx, a, b - a, own_lo, hi)
+    # the short last batch: everybody computes it, everybody merges what falls into its own rows
+    if short[1] > short[0]:
+        sb = _forward_rows(pipe, d_idx, first_short, nwin - first_short, short[0], short[1])
+        lo_, hi_ = max(short[0], own_lo), min(short[1], own_hi)
+        if hi_ > lo_:
+            torch.maximum(local[lo_ - own_lo:hi_ - own_lo], sb[lo_ - short[0]:hi_ - short[0]], out=local[lo_ - own_lo:hi_ - own_lo])
+    # spill rows -> their owners (all ranks derive the same list of transfers)
+    ops, recvs, keep = [], [], []
+    for src in range(world):
+        sa, sbw = shares[src]
+        s_lo, s_hi = owned[src][1], (min((sbw - 1) * pipe.step + T, n) if sbw > sa else owned[src][1])
+        for dst in range(src + 1, world):
+            lo_, hi_ = max(s_lo, owned[dst][0]), min(s_hi, owned[dst][1])
+            if hi_ <= lo_:
+                continue
+            if rank == src:
+                t = local[lo_ - own_lo:hi_ - own_lo].to(cdev).contiguous()
+                keep.append(t)
+                ops.append(dist.P2POp(dist.isend, t, dst))
+            elif rank == dst:
+                t = torch.empty((hi_ - lo_, C_), dtype=torch.float32, device=cdev)
+                recvs.append((lo_, hi_, t))
+                ops.append(dist.P2POp(dist.irecv, t, src))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for lo_, hi_, t in recvs:
+        torch.maximum(local[lo_ - own_lo:hi_ - own_lo], t.to(dev), out=local[lo_ - own_lo:hi_ - own_lo])
+    nown = own_hi - own_lo
+    mine = local[:nown]
+    counts = [h - l for l, h in owned]
+    cap = max(max(counts), 1)
+    if pipe.use_mss:
+        scores = torch.empty(max(nown, 1), dtype=torch.float64, device=dev)
+        cls = torch.empty(max(nown, 1), dtype=torch.int8, device=dev)
+        if nown:
+            check(L.dgrp_scores(mine.data_ptr(), nown, C_, scores.data_ptr(), cls.data_ptr(), stream_ptr()), "dgrp_scores")
+        send_s = torch.zeros(cap, dtype=torch.float32, device=cdev)
+        send_c = torch.zeros(cap, dtype=torch.int8, device=cdev)
+        send_s[:nown] = scores[:nown].to(torch.float32).to(cdev)          # exact: the score IS a float32 (prediction.py:53-57)
+        send_c[:nown] = cls[:nown].to(cdev)
+        parts_s = [torch.empty_like(send_s) for _ in range(world)] if rank == 0 else None
+        parts_c = [torch.empty_like(send_c) for _ in range(world)] if rank == 0 else None
+        dist.gather(send_s, parts_s, dst=0)
+        dist.gather(send_c, parts_c, dst=0)
+        if rank != 0:
+            return np.zeros(0, SEGMENT_DTYPE)
+        all_s = torch.cat([p[:c].to(dev) for p, c in zip(parts_s, counts)]).to(torch.float64)
+        all_c = torch.cat([p[:c].to(dev) for p, c in zip(parts_c, counts)])
+        labels = pipe.labels_from_scores(all_s, all_c)
+    else:
+        send = torch.zeros((cap, C_), dtype=torch.float32, device=cdev)
+        send[:nown] = mine.to(cdev)
+        parts = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, parts, dst=0)
+        if rank != 0:
+            return np.zeros(0, SEGMENT_DTYPE)
+        merged = torch.cat([p[:c].to(dev) for p, c in zip(parts, counts)])
+        labels = pipe.labels(merged)
+    return pipe.segments(labels, startpos, contig)
+
+
+def raise_together(err: Exception = None) -> None:
+    """Collective error check: if any rank holds an exception, EVERY rank raises (its own, or a RuntimeError naming the
+    failing rank) instead of the others blocking in the next collective until it times out."""
+    if not dist.is_initialized():
+        if err is not None:
+            raise err
+        return
+    msgs = [None] * dist.get_world_size()
+    dist.all_gather_object(msgs, None if err is None else f"{type(err).__name__}: {err}")
+    if err is not None:
+        raise err
+    bad = [(k, msg) for k, msg in enumerate(msgs) if msg is not None]
+    if bad:
+        raise RuntimeError(f"rank {bad[0][0]} failed: {bad[0][1]}")

@@ -206,7 +206,13 @@ class DeviceModel:
         x = torch.as_tensor(np.asarray(batch) if not isinstance(batch, torch.Tensor) else batch)
         if x.ndim != 3 or x.shape[1] != self.vecsize or x.shape[2] != 5:
             raise ValueError(f"expected a batch of shape [b, {self.vecsize}, 5], got {tuple(x.shape)}")
-        idx = x.to(dev).argmax(dim=2).to(torch.uint8).reshape(-1).contiguous()
+        x = x.to(dev)
+        # the device path looks the input projection up by base (one-hot input): anything else -- soft labels, random
+        # floats, an all-zero row -- would silently be read as the argmax base, where Keras computes the real projection
+        if x.numel() and not bool((((x == 0) | (x == 1)).all(dim=2) & (x.sum(dim=2) == 1)).all()):
+            raise ValueError("predict_on_batch takes one-hot batches (every [b, t, :] row holds a single 1): the device path looks "
+                             "the input projection up by base")
+        idx = x.argmax(dim=2).to(torch.uint8).reshape(-1).contiguous()
         b = x.shape[0]
         if b == 0:
             return np.zeros((0, self.vecsize, self.classes), np.float32)
@@ -316,21 +322,30 @@ class ContigPipeline:
         L = lib()
         n, c = merged.shape
         dev = merged.device
-        labels = torch.empty(n, dtype=torch.int8, device=dev)
         if n == 0:
-            return labels
+            return torch.empty(0, dtype=torch.int8, device=dev)
         if self.use_mss:
             scores = torch.empty(n, dtype=torch.float64, device=dev)
             cls = torch.empty(n, dtype=torch.int8, device=dev)
             check(L.dgrp_scores(_ptr(merged), n, c, _ptr(scores), _ptr(cls), stream_ptr()), "dgrp_scores")
-            wb = L.dgrp_mss_workspace_bytes(n)
-            work = torch.empty(wb, dtype=torch.uint8, device=dev)
-            check(L.dgrp_mss_labels(_ptr(scores), _ptr(cls), n, c, self.min_mss_len, self.xdrop_len, _ptr(labels),
-                                    None, _ptr(work), wb, stream_ptr()), "dgrp_mss_labels")
-        else:
-            work = torch.empty(4096, dtype=torch.uint8, device=dev)
-            check(L.dgrp_softmax_labels(_ptr(merged), n, c, None, _ptr(labels), _ptr(work), work.numel(),
-                                        stream_ptr()), "dgrp_softmax_labels")
+            return self.labels_from_scores(scores, cls)
+        labels = torch.empty(n, dtype=torch.int8, device=dev)
+        work = torch.empty(4096, dtype=torch.uint8, device=dev)
+        check(L.dgrp_softmax_labels(_ptr(merged), n, c, None, _ptr(labels), _ptr(work), work.numel(),
+                                    stream_ptr()), "dgrp_softmax_labels")
+        return labels
+
+    # A9-A10 on scores / classes that are already there (distributed.run_split assembles them from all ranks)
+    def labels_from_scores(self, scores: torch.Tensor, cls: torch.Tensor) -> torch.Tensor:
+        L = lib()
+        n, dev = scores.numel(), scores.device
+        labels = torch.empty(n, dtype=torch.int8, device=dev)
+        if n == 0:
+            return labels
+        wb = L.dgrp_mss_workspace_bytes(n)
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        check(L.dgrp_mss_labels(_ptr(scores), _ptr(cls), n, self.model.classes, self.min_mss_len, self.xdrop_len, _ptr(labels),
+                                None, _ptr(work), wb, stream_ptr()), "dgrp_mss_labels")
         return labels
 
     # A11

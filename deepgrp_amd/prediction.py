@@ -45,14 +45,18 @@ class WindowDataset:
             if self.channels != 5:
                 raise ValueError("the device path needs the 5-channel one-hot encoding")
             dev = require_gpu()
-            self._d_idx = torch.from_numpy(np.ascontiguousarray(self._host)).to(dev).argmax(dim=0).to(torch.uint8).contiguous()
+            d = torch.from_numpy(np.ascontiguousarray(self._host)).to(dev)
+            # one-hot columns only (what one_hot_encode_dna_sequence produces): the device path looks the input projection up by base
+            if d.numel() and not bool((((d == 0) | (d == 1)).all(dim=0) & (d.sum(dim=0) == 1)).all()):
+                raise ValueError("the device path takes one-hot data (every column holds a single 1)")
+            self._d_idx = d.argmax(dim=0).to(torch.uint8).contiguous()
         return self._d_idx
 
     def __len__(self) -> int:
         return (self.nwin + self.batch_size - 1) // self.batch_size
 
     def __iter__(self) -> Iterator[np.ndarray]:
-        if self.channels == 5 and set(np.unique(self._host)) <= {0, 1}:
+        if self.channels == 5 and set(np.unique(self._host)) <= {0, 1} and bool((self._host.sum(axis=0) == 1).all()):
             d_idx = self.device_index()
             for w0 in range(0, self.nwin, self.batch_size):
                 nw = min(self.batch_size, self.nwin - w0)

@@ -16,6 +16,7 @@ import torch
 from .fasta import DeviceRecord
 from .pipeline import ContigPipeline
 
+_BATCH = object()             # key slot of a work item that is a batch of records (never equal to a user's key, e.g. a header "batch")
 SMALL_RECORD = 1 << 18        # bases: up to here a record may join a batch
 BATCH_RECORDS = 4096
 BATCH_BYTES = 4 << 30         # workspace a batch may ask for
@@ -71,7 +72,7 @@ class RecordRunner:
         return cost
 
     def work_items(self, records: Iterable[Tuple[object, object]]) -> Iterator[Tuple[object, object]]:
-        """Consecutive short records of one ingest buffer become one ("batch", [(key, record), ...]) item, everything
+        """Consecutive short records of one ingest buffer become one (_BATCH, [(key, record), ...]) item, everything
         else stays (key, record)."""
         group: List[Tuple[object, DeviceRecord]] = []
         cost = 0
@@ -81,17 +82,17 @@ class RecordRunner:
             if small:
                 c = self._batch_cost(rec.length)
                 if group and (group[0][1].base is not rec.base or len(group) >= BATCH_RECORDS or cost + c > BATCH_BYTES):
-                    yield "batch", group
+                    yield _BATCH, group
                     group, cost = [], 0
                 group.append((key, rec))
                 cost += c
             else:
                 if group:
-                    yield "batch", group
+                    yield _BATCH, group
                     group, cost = [], 0
                 yield key, rec
         if group:
-            yield "batch", group
+            yield _BATCH, group
 
     def run_item(self, item):
         if isinstance(item, list):                        # a batch: rows of all its records, contig = position in the batch
@@ -143,7 +144,7 @@ class RecordRunner:
 
     def results(self, records: Iterable[Tuple[object, object]]):
         for key, result in self.in_order(self.work_items(records)):
-            if key == "batch":
+            if key is _BATCH:
                 keys, rows = result
                 yield "batch", keys, rows
             else:

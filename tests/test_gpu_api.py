@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden
+from conftest import GOLDEN, ROOT, golden
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -395,8 +395,7 @@ def test_fasta_device_ingest_matches_reference_loop(orc, tmp_path):
         want, werr = [], None
         try:
             with open(path, "r") as fh:
-                for h, s in read_multi_fasta_lines(fh):
-                    want.append((h, s))
+                want = orc.read_multi_fasta(fh)            # the checker's statement of __main__.py:20-43, not the package's own loop
         except Exception as e:           # noqa: BLE001
             werr = type(e).__name__
         got, gerr, ndev = [], None, 0
@@ -437,7 +436,9 @@ def test_fasta_device_ingest_groups(orc, tmp_path, group_records):
     path = tmp_path / "g.fa"
     path.write_bytes(text.encode())
     with open(path) as fh:
-        want = list(read_multi_fasta_lines(fh))
+        want = orc.read_multi_fasta(fh)
+    with open(path) as fh:
+        assert list(read_multi_fasta_lines(fh)) == want      # the package's line loop (stdin path, odd records) says the same
     got = []
     for h, rec in read_multi_fasta_device(str(path), group_records=group_records):
         if isinstance(rec, DeviceRecord):
@@ -520,3 +521,43 @@ def test_predict_record_equals_staged_path(orc, kind):
         check(L.dgrp_predict_record(m.handle, d_idx.data_ptr(), d_idx.numel(), s, B, 4, 6, 1, 0, 0, rec.data_ptr(), 8, C.byref(cnt),
                                     work.data_ptr(), 256, stream_ptr()), "dgrp_predict_record")
     m.close()
+
+
+def test_cli_console_forms_and_npz_input(tmp_path):
+    """The `deepgrp` console script's callable (pyproject.toml) in the README form `deepgrp <model> <fasta>` and in the
+    reference's form `deepgrp [flags] predict <model> <FASTA>`: same TSV.  And the `<fasta>.gz.npz` one-hot file that
+    `preprocess_sequence` writes as an alternative input: same rows as the FASTA it was made from."""
+    import gzip
+    import importlib
+    import tomli
+    from deepgrp_amd import model as dgmodel, synthetic
+    with open(os.path.join(ROOT, "pyproject.toml"), "rb") as fh:
+        scripts = tomli.load(fh)["project"]["scripts"]
+    entry = lambda name: getattr(importlib.import_module(scripts[name].split(":")[0]), scripts[name].split(":")[1])
+    w = synthetic.trained_weights()
+    mpath = str(tmp_path / "m.hdf5")
+    dgmodel.save_keras_hdf5(mpath, w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, vecsize=200)
+    raw = synthetic.synthetic_chromosome(150_000, contig=5, flank=700)
+    fa = tmp_path / "one.fa"
+    text = b">chrZ some text\n" + b"\n".join(raw[i:i + 60] for i in range(0, len(raw), 60)) + b"\n"
+    fa.write_bytes(text)
+    out1, out2, out3 = (str(tmp_path / n) for n in ("a.tsv", "b.tsv", "c.tsv"))
+    # README form has no place for --output: capture stdout
+    import contextlib
+    import io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        entry("deepgrp")([mpath, str(fa)])
+    open(out1, "w").write(buf.getvalue())
+    entry("deepgrp")(["predict", mpath, str(fa), "--output", out2])
+    assert open(out1).read() == open(out2).read() and open(out2).read().count("\n") > 20
+    gz = tmp_path / "one.fa.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(text)
+    entry("preprocess_sequence")([str(gz)])
+    npz = str(gz) + ".npz"
+    assert os.path.exists(npz)
+    entry("deepgrp")(["predict", mpath, npz, "--output", out3])
+    rows = lambda p: [ln.split("\t")[2:] for ln in open(p).read().splitlines()]
+    assert rows(out3) == rows(out2)
+    assert {ln.split("\t")[1] for ln in open(out3).read().splitlines()} == {"one.fa.gz"}

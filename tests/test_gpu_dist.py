@@ -54,26 +54,33 @@ def _split_worker(rank, world, port, fasta, model, out):
     main(["-b", "7", "predict", model, fasta, "--output", out, "--split_contigs"])
 
 
-def test_split_contigs_two_ranks_on_one_gpu(tmp_path):
-    """--split_contigs with 2 ranks (both on GPU 0, gloo as the transport) gives the same TSV, byte for
-    byte, as a single-process run: the window shares overlap by T - step rows and max-combine exactly."""
+@pytest.mark.parametrize("kind,world", [("gru128", 2), ("attention_defaults", 2), ("attention_defaults", 3)])
+def test_split_contigs_ranks_on_one_gpu(tmp_path, kind, world):
+    """--split_contigs (distributed.run_split) with 2 or 3 ranks (all on GPU 0, gloo as the transport) gives the same TSV,
+    byte for byte, as a single-process run: window shares spill T - step rows into the next rank's rows and max-combine
+    exactly, the short last batch (-b 7: SURVEY Q2) is placed by every rank, scores travel as float32 + int8.  Both the
+    benchmark's model and a model of the reference's default shape (defaults.toml: 60 units, window 342, attention)."""
     import torch.multiprocessing as mp
     from deepgrp_amd import model as dgmodel, synthetic
     from deepgrp_amd.__main__ import main
-    w = synthetic.trained_weights()
     mpath = str(tmp_path / "m.hdf5")
-    dgmodel.save_keras_hdf5(mpath, w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, vecsize=200)
+    if kind == "gru128":
+        w = synthetic.trained_weights()
+        dgmodel.save_keras_hdf5(mpath, w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, vecsize=200)
+    else:
+        w = synthetic.synthetic_weights(60, 5, attention=True, seed=5, gain=2.0)
+        dgmodel.save_keras_hdf5(mpath, w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=342)
     fa = tmp_path / "two.fa"
     with open(fa, "wb") as fh:
-        for k, n in enumerate((300_000, 123_457)):
-            raw = synthetic.synthetic_chromosome(n, contig=k, flank=1000)
+        for k, n in enumerate((300_000, 123_457, 500, 2_000)):       # the last two: fewer windows than ranks x 16 / than one batch
+            raw = synthetic.synthetic_chromosome(n, contig=k, flank=100)
             fh.write(b">rec%d\n" % k + b"\n".join(raw[i:i + 70] for i in range(0, len(raw), 70)) + b"\n")
     single = str(tmp_path / "single.tsv")
     main(["-b", "7", "predict", mpath, str(fa), "--output", single])
     split = str(tmp_path / "split.tsv")
     ctx = mp.get_context("spawn")
     port = 29800 + os.getpid() % 150
-    procs = [ctx.Process(target=_split_worker, args=(r, 2, port, str(fa), mpath, split)) for r in range(2)]
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, str(fa), mpath, split)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -224,6 +224,10 @@ def test_predict_on_batch_keras_style(dev, orc):
     got = dm.predict_on_batch(batch)
     want = orc.nn_forward(idx, w, 24, 0, 6, np.float64)
     assert got.shape == (6, 24, 5) and np.abs(got - want).max() < 1e-3
+    # anything but one-hot rows is refused (Keras would compute the real input projection; the device path looks it up by base)
+    for bad in (rng.random((2, 24, 5)).astype(np.float32), np.zeros((1, 24, 5), np.float32), batch[:1] * 0.5):
+        with pytest.raises(ValueError, match="one-hot"):
+            dm.predict_on_batch(bad)
     dm.close()
 
 

@@ -540,7 +540,7 @@ def test_record_runner_grouping_and_order():
             ("r7", DeviceRecord(1, None, 10, b, 400)), ("r8", DeviceRecord(1, None, 10, b, 500))]
     r = rn.RecordRunner(FakePipe(), workers=3)
     items = list(r.work_items(recs))
-    shape = [(k, [kk for kk, _ in v]) if k == "batch" else (k, None) for k, v in items]
+    shape = [("batch", [kk for kk, _ in v]) if k is rn._BATCH else (k, None) for k, v in items]
     assert shape == [("batch", ["r0", "r1"]), ("batch", ["r2"]), ("r3", None), ("batch", ["r4"]), ("r5", None), ("r6", None),
                      ("batch", ["r7", "r8"])]
     out = list(r.results(recs))
@@ -556,6 +556,99 @@ def test_record_runner_grouping_and_order():
     assert got == [["r0", "r1"], ["r2"]]
     with pytest.raises(RuntimeError, match="boom"):
         list(r.results([("x", "ACGT"), ("y", "boom"), ("z", "AC")]))
+    # a record whose header IS the word "batch" (the key slot once carried that string for batches): on its own as text
+    # (stdin / odd records), as a long device record, and inside a batch -- every header the reference accepts works here
+    named = [("batch", "ACGT"), ("batch", DeviceRecord(0, None, rn.SMALL_RECORD + 1, b, 0)), ("batch", DeviceRecord(0, None, 5, b, 9)),
+             ("other", DeviceRecord(0, None, 6, b, 20))]
+    res = list(r.results(named))
+    assert [(kind, key) for kind, key, _rows in res] == [("one", "batch"), ("one", "batch"), ("batch", ["batch", "other"])]
+    assert res[0][2]["start"].tolist() == [4] and res[2][2]["contig"].tolist() == [0, 1]
     # TSV text of a batch = the per-record texts one after the other
     rows = out[0][2]
     assert rn.rows_text_batch("f.fa", ["r0", "r1"], rows) == rn.rows_text("f.fa", "r0", rows[:1]) + rn.rows_text("f.fa", "r1", rows[1:])
+
+
+def test_packaging_console_scripts():
+    """pyproject.toml declares the reference's three commands (/root/reference pyproject.toml:34-37) on this package's callables."""
+    import importlib
+    import tomli
+    with open(os.path.join(ROOT, "pyproject.toml"), "rb") as fh:
+        meta = tomli.load(fh)
+    scripts = meta["project"]["scripts"]
+    assert set(scripts) == {"deepgrp", "parse_rm", "preprocess_sequence"}
+    assert scripts["deepgrp"] == "deepgrp_amd.__main__:main"
+    for target in scripts.values():
+        mod, fn = target.split(":")
+        assert callable(getattr(importlib.import_module(mod), fn))
+    assert "deepgrp_amd" in meta["tool"]["setuptools"]["packages"]
+
+
+def test_cli_grammar_both_forms():
+    """`deepgrp <modelfile> <fastafile>` (README.rst:94) and `deepgrp [flags] predict <model> <FASTA>...` parse to
+    the same command; flags keep the reference's defaults (__main__.py:103-148)."""
+    from deepgrp_amd.__main__ import CommandLineParser
+    a = CommandLineParser().parse_args(["m.hdf5", "x.fa"]).args
+    b = CommandLineParser().parse_args(["predict", "m.hdf5", "x.fa"]).args
+    c = CommandLineParser().parse_args(["-b", "7", "-s", "25", "m.hdf5", "x.fa", "y.fa.gz.npz"]).args
+    assert a.command == b.command == c.command == "predict" and a.model == b.model == "m.hdf5" and a.FASTA == b.FASTA == ["x.fa"]
+    assert (a.batch_size, a.step_size, a.xdrop_length, a.min_mss_length, a.output, a.no_use_mss) == (256, 50, 50, 50, "-", False)
+    assert (c.batch_size, c.step_size, c.FASTA) == (7, 25, ["x.fa", "y.fa.gz.npz"])
+
+
+def test_split_plan_partitions_rows_and_covers_spills():
+    """distributed.split_plan: the owned row ranges partition [0, n), a rank's full-batch windows start inside its own range,
+    every row a window writes is owned by its rank or by one behind it (the spill transfers), and the short last batch
+    lands where the reference puts it -- for window counts around the share / batch boundaries."""
+    from deepgrp_amd.distributed import split_plan
+    for T, s, B in ((200, 50, 256), (500, 25, 256), (40, 7, 4), (30, 300, 3)):
+        for world in (1, 2, 3, 8):
+            for n in (T, T + 1, T + s * 5, T + s * (B - 1) + 3, T + s * B + 1, T + s * (B * 3 + 17) + 9, T + s * (16 * world * 2 + 5)):
+                nwin, first_short, shares, owned, short = split_plan(n, T, s, B, world)
+                assert nwin == len(range(0, n - T, s)) and first_short == nwin // B * B
+                assert owned[0][0] == 0 and owned[-1][1] == n and all(owned[k][1] == owned[k + 1][0] for k in range(world - 1))
+                assert shares[0][0] == 0 and shares[-1][1] == first_short and all(shares[k][1] == shares[k + 1][0] for k in range(world - 1))
+                for k, (a, b) in enumerate(shares):
+                    for w in (a, b - 1) if b > a else ():
+                        lo, hi = w * s, min(w * s + T, n)
+                        assert owned[k][0] <= lo                                    # never writes in front of its own rows
+                        # rows behind its own range belong to later ranks: all covered by the ownership partition
+                        assert hi <= n
+                r = nwin - first_short
+                if r:
+                    nfull = nwin // B
+                    assert short == (nfull * r * s, min((nfull * r + r - 1) * s + T, n))
+                else:
+                    assert short == (0, 0)
+
+
+def _raise_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo")
+    from deepgrp_amd.distributed import raise_together
+    raise_together(None)                                                      # nobody failed: returns everywhere
+    try:
+        raise_together(ValueError("negative dimensions are not allowed") if rank == 1 else None)
+        q.put((rank, "no error"))
+    except Exception as e:                                                    # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_raise_together_gloo_world2():
+    """A per-record error on one rank (the all-N ValueError of sequence.pyx:32) reaches every rank before the next
+    collective instead of leaving the others blocked in the gather."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_raise_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] == "ValueError: negative dimensions are not allowed"
+    assert got[0].startswith("RuntimeError: rank 1 failed: ValueError")

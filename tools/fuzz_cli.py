@@ -8,6 +8,19 @@ from deepgrp_amd import model as dgmodel
 from deepgrp_amd.__main__ import main
 from deepgrp_amd.pipeline import upload_sequence
 
+
+def say(*a, **_kw):
+    """Progress goes to stdout AND to gpurun_out/<tool>.progress: a long sweep behind a pipe (`| tail`) shows no output until
+    the pipe ends, which gpurun takes for a hang (profiles/r01_fuzz_summary.txt's run was killed that way)."""
+    import os as _os
+    line = " ".join(str(x) for x in a)
+    print(line, flush=True)
+    _os.makedirs("gpurun_out", exist_ok=True)
+    with open(_os.path.join("gpurun_out", _os.path.basename(__file__)[:-3] + ".progress"), "a") as fh:
+        fh.write(line + "\n")
+
+
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 d = tempfile.mkdtemp()
@@ -61,9 +74,9 @@ while time.time() < t_end:
         got = open(out).read()
         assert got == "".join(want), "TSV differs"
     except Exception as e:      # noqa: BLE001
-        print("FAIL", tag, "->", repr(e)[:300], flush=True)
+        say("FAIL", tag, "->", repr(e)[:300], flush=True)
         import shutil; shutil.copy(fa, "gpurun_out/fuzz_cli_fail.fa")
         sys.exit(1)
     if it % 20 == 0:
-        print(it, "runs ok", flush=True)
-print("done:", it, "runs ok")
+        say(it, "runs ok", flush=True)
+say("done:", it, "runs ok")

@@ -6,6 +6,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc
 from deepgrp_amd.fasta import DeviceRecord, read_multi_fasta_device, read_multi_fasta_lines
 
+
+def say(*a, **_kw):
+    """Progress goes to stdout AND to gpurun_out/<tool>.progress: a long sweep behind a pipe (`| tail`) shows no output until
+    the pipe ends, which gpurun takes for a hang (profiles/r01_fuzz_summary.txt's run was killed that way)."""
+    import os as _os
+    line = " ".join(str(x) for x in a)
+    print(line, flush=True)
+    _os.makedirs("gpurun_out", exist_ok=True)
+    with open(_os.path.join("gpurun_out", _os.path.basename(__file__)[:-3] + ".progress"), "a") as fh:
+        fh.write(line + "\n")
+
+
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 d = tempfile.mkdtemp()
@@ -49,8 +62,8 @@ while time.time() < t_end:
             if (h, st, n) != (wh, wst, wn) or not np.array_equal(idx, orc.encode_idx(ws.encode()[wst:wst + max(wn, 0)])):
                 ok = False
     if not ok:
-        print("FAIL", repr(data), "want", werr, [(h, len(s)) for h, s in want], "got", gerr, [(g[0], g[2]) for g in got], flush=True)
+        say("FAIL", repr(data), "want", werr, [(h, len(s)) for h, s in want], "got", gerr, [(g[0], g[2]) for g in got], flush=True)
         sys.exit(1)
     if it % 200 == 0:
-        print(it, "files ok", flush=True)
-print("done:", it, "files ok")
+        say(it, "files ok", flush=True)
+say("done:", it, "files ok")

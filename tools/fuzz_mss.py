@@ -7,6 +7,19 @@ from oracle import oracle as orc
 from deepgrp_amd._lib import check, lib
 from deepgrp_amd.pipeline import require_gpu, stream_ptr
 
+
+def say(*a, **_kw):
+    """Progress goes to stdout AND to gpurun_out/<tool>.progress: a long sweep behind a pipe (`| tail`) shows no output until
+    the pipe ends, which gpurun takes for a hang (profiles/r01_fuzz_summary.txt's run was killed that way)."""
+    import os as _os
+    line = " ".join(str(x) for x in a)
+    print(line, flush=True)
+    _os.makedirs("gpurun_out", exist_ok=True)
+    with open(_os.path.join("gpurun_out", _os.path.basename(__file__)[:-3] + ".progress"), "a") as fh:
+        fh.write(line + "\n")
+
+
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 dev, L = require_gpu(), lib()
@@ -70,8 +83,8 @@ while time.time() < t_end:
         ok = all(np.array_equal(got[int(starts[i]):int(starts[i]) + n], want[int(starts[i]):int(starts[i]) + n]) for i, n in enumerate(lens))
         what = f"batch lens={lens}"
     if not ok:
-        print("FAIL", what, "ml/xd", ml, xd, flush=True)
+        say("FAIL", what, "ml/xd", ml, xd, flush=True)
         sys.exit(1)
     if it % 50 == 0:
-        print(it, "cases ok", flush=True)
-print("done:", it, "cases ok")
+        say(it, "cases ok", flush=True)
+say("done:", it, "cases ok")

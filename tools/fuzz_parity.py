@@ -7,6 +7,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as orc
 from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, require_gpu
 
+
+def say(*a, **_kw):
+    """Progress goes to stdout AND to gpurun_out/<tool>.progress: a long sweep behind a pipe (`| tail`) shows no output until
+    the pipe ends, which gpurun takes for a hang (profiles/r01_fuzz_summary.txt's run was killed that way)."""
+    import os as _os
+    line = " ".join(str(x) for x in a)
+    print(line, flush=True)
+    _os.makedirs("gpurun_out", exist_ok=True)
+    with open(_os.path.join("gpurun_out", _os.path.basename(__file__)[:-3] + ".progress"), "a") as fh:
+        fh.write(line + "\n")
+
+
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120
 dev = require_gpu()
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -71,9 +84,9 @@ while time.time() < t_end:
             got = pipe.run_batch(d_base, offs, lens, [11] * len(lens), list(range(len(lens))))
             assert np.array_equal(got, np.concatenate(singles)), "batch != record path"
     except Exception as e:      # noqa: BLE001
-        print("FAIL", tag, "->", repr(e), flush=True)
+        say("FAIL", tag, "->", repr(e), flush=True)
         sys.exit(1)
     m.close()
     if it % 20 == 0:
-        print(f"{it} configurations ok, worst forward error {worst:.2e} (fp16 operands) {worst_split:.2e} (split operands)", flush=True)
-print(f"done: {it} configurations ok, worst forward error {worst:.2e} (fp16 operands) {worst_split:.2e} (split operands)")
+        say(f"{it} configurations ok, worst forward error {worst:.2e} (fp16 operands) {worst_split:.2e} (split operands)", flush=True)
+say(f"done: {it} configurations ok, worst forward error {worst:.2e} (fp16 operands) {worst_split:.2e} (split operands)")
