@@ -180,6 +180,29 @@ static hipError_t upload_raw(dgrp_model *m, const float *kernel, const float *re
     return e;
 }
 
+// recurrent fragments for rnn_split_stream_kernel: [NW][KS][2 G][64][8], hi halves of gates 0..G-1 then their lo halves per k-step
+// (lane l of wave w: rows 16 ks + 8 (l >> 5) + j of column g*u + unit, unit = 32 w + (l & 31), scaled by gs[g])
+static hipError_t upload_stream(dgrp_model *m, const float *rec, int G, const float *gs)
+{
+    const int KS = m->KS, u = m->u, ld = G * u;
+    std::vector<uint16_t> st((size_t)m->NW * KS * 2 * G * 64 * 8, 0);
+    for (int w = 0; w < m->NW; ++w)
+        for (int ks = 0; ks < KS; ++ks)
+            for (int g = 0; g < G; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int unit = 32 * w + (l & 31), k = 16 * ks + 8 * (l >> 5) + j;
+                        if (unit >= u || k >= u) continue;
+                        const float x = gs[g] * rec[(size_t)k * ld + g * u + unit];
+                        const uint16_t hi = f2h(x);
+                        st[((((size_t)w * KS + ks) * 2 * G + g) * 64 + l) * 8 + j] = hi;
+                        st[((((size_t)w * KS + ks) * 2 * G + G + g) * 64 + l) * 8 + j] = f2h(x - h2f(hi));
+                    }
+    hipError_t e = hipMalloc((void **)&m->d_stream, st.size() * 2);
+    if (e == hipSuccess) e = hipMemcpy(m->d_stream, st.data(), st.size() * 2, hipMemcpyHostToDevice);
+    return e;
+}
+
 DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *kernel,
                                   const float *rec, const float *bias, const float *scale, const float *ffk,
                                   const float *ffb)
@@ -202,7 +225,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     m->KS = m->UP / 16;
     m->nfrag = 3 * (m->KS + 1) + 3;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
-    m->d_pack_lo = nullptr; m->precision = 0; m->d_pack16 = nullptr; m->d_xtab = nullptr;
+    m->d_pack_lo = nullptr; m->precision = 0; m->d_pack16 = nullptr; m->d_xtab = nullptr; m->d_stream = nullptr;
     const int KS = m->KS, NF = m->nfrag, u3 = 3 * u;
     // The update z*h + (1-z)*tanh(g) can be written with ONE reciprocal, of (1 + 2^az)(1 + 2^ag), if that
     // product cannot overflow: |h| <= 1 and 0 < r < 1 bound both pre-activations by the weights' absolute
@@ -360,6 +383,13 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
         const char *pe = getenv("DGRP_GRU_PRECISION");
         m->precision = !(pe && pe[0] == '0') ? 1 : 0;
     }
+    if (m->NW > 4) {
+        // 129-256 units: the streamed split-operand kernel (rnn_stream.hip) is the default, the fp16-operand kernel the --fast mode
+        static const float gs3[3] = { -1.4426950408889634f, -1.4426950408889634f, 2.8853900817779268f };
+        CREATE_HIP(upload_stream(m, rec, 3, gs3));
+        const char *pe = getenv("DGRP_GRU_PRECISION");
+        m->precision = !(pe && pe[0] == '0') ? 1 : 0;
+    }
 #undef CREATE_HIP
     *out = m;
     return DGRP_OK;
@@ -384,7 +414,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     m->KS = m->UP / 16;
     m->nfrag = 4 * (m->KS + 1) + 2;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
-    m->d_pack_lo = nullptr; m->precision = 0; m->d_pack16 = nullptr; m->d_xtab = nullptr;
+    m->d_pack_lo = nullptr; m->precision = 0; m->d_pack16 = nullptr; m->d_xtab = nullptr; m->d_stream = nullptr;
     const int KS = m->KS, NF = m->nfrag, u4 = 4 * u;
     std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
     frag_writer fw{ pack, NF };
@@ -411,6 +441,12 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     if (e == hipSuccess) e = hipMalloc((void **)&m->d_ffb, sizeof(ffb16));
     if (e == hipSuccess) e = hipMemcpy(m->d_ffb, ffb16, sizeof(ffb16), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = upload_raw(m, kernel, rec, bias, u4, ffk, (int64_t)u * C, ffb, nullptr);
+    if (e == hipSuccess) {
+        static const float gs4[4] = { -1.4426950408889634f, -1.4426950408889634f, 2.8853900817779268f, -1.4426950408889634f };
+        e = upload_stream(m, rec, 4, gs4);
+        const char *pe = getenv("DGRP_GRU_PRECISION");
+        m->precision = !(pe && pe[0] == '0') ? 1 : 0;          // split operands by default, like every other model
+    }
     if (e != hipSuccess) {
         dgrp_set_error("dgrp_model_create_lstm: %s", hipGetErrorString(e));
         dgrp_model_destroy(m);
@@ -431,6 +467,7 @@ DGRP_EXPORT int dgrp_model_destroy(dgrp_model *m)
     if (m->d_pack_lo) (void)hipFree(m->d_pack_lo);
     if (m->d_pack16) (void)hipFree(m->d_pack16);
     if (m->d_xtab) (void)hipFree(m->d_xtab);
+    if (m->d_stream) (void)hipFree(m->d_stream);
     delete m;
     return DGRP_OK;
 }
@@ -455,8 +492,7 @@ DGRP_EXPORT int dgrp_model_set_precision(dgrp_model *m, int level)
 {
     DGRP_REQUIRE(m, "dgrp_model_set_precision: NULL model");
     DGRP_REQUIRE(level == 0 || level == 1, "dgrp_model_set_precision: level must be 0 (fp16 operands) or 1 (split operands)");
-    DGRP_REQUIRE(level == 0 || (m->cell == 0 && m->d_pack_lo),
-                 "dgrp_model_set_precision: the split-operand kernel covers GRU models up to 128 units");
+    DGRP_REQUIRE(level == 0 || m->d_pack_lo || m->d_stream, "dgrp_model_set_precision: this model has no split-operand kernel");
     m->precision = level;
     return DGRP_OK;
 }

@@ -19,6 +19,9 @@ struct dgrp_model {
     // and the input projection as a table [5 bases][4 kinds r, g (recurrent bias only), z, x][128 units] fp32, exp2 domain
     uint4 *d_pack16;
     float *d_xtab;
+    // GRU with 129-256 units and LSTM, for rnn_split_stream_kernel (rnn_stream.hip): the recurrent kernel as 32x32x16 fragments, hi and
+    // lo halves, in consumption order [NW][KS][2 G][64] (k-step major; G hi fragments in pack gate order, then the G lo fragments), or NULL
+    uint4 *d_stream;
     float *d_ffb;     // [16] dense bias, zero padded
     float *d_scale;   // [UP] attention scale (zero padded) or NULL
     float *d_wtop;    // [UP][16] rows of the dense kernel that multiply the context vector, or NULL
@@ -43,6 +46,9 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
 int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
                           int merge, int64_t n, const void *d_avg, const float *d_pl, float *d_out,
                           hipStream_t stream);
+// rnn_stream.hip: the streamed split-operand kernel (cell 0 = GRU with 5..8 waves, 1 = LSTM with 1..4 waves)
+struct gru_params;
+int dgrp_stream_launch(const gru_params &p, int cell, int NW, int64_t groups, size_t lds, hipStream_t stream);
 // batched records (mode 0): see gru_kernel.hip
 int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, const void *d_recs, const int64_t *d_wg_first,
                           int64_t nrec, int64_t total_groups, int mode, float *d_out, void *d_avg, hipStream_t stream);

@@ -1079,7 +1079,7 @@ static int launch_split(const gru_params &p, int64_t groups, size_t lds, hipStre
 }
 
 // split-operand kernel selected (dgrp_model_set_precision) and applicable to this launch
-static bool use_split(const dgrp_model *m, int) { return m->precision == 1 && m->cell == 0 && m->NW <= 4 && m->d_pack_lo; }
+static bool use_split(const dgrp_model *m, int) { return m->precision == 1 && ((m->cell == 0 && m->NW <= 4 && m->d_pack_lo) || m->d_stream); }
 
 template <int NW>
 static int launch_lstm(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
@@ -1144,7 +1144,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
 #endif
     const bool split = use_split(m, mode);
     p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
-    p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0;
+    p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0; p.stream = m->d_stream;
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
     if (split && split2_applies(m)) {
@@ -1160,6 +1160,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, (m->NW > 4 ? 144 : 72) * 1024);
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T,
                  gru_lds_seq(p.Tp));
+    if (split && m->d_stream) return dgrp_stream_launch(p, m->cell, m->NW, groups, lds, stream);
     if (split) {
         switch (m->NW) {
         case 1: return launch_split<1>(p, groups, lds, stream);
@@ -1222,7 +1223,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     p.recs = (const gru_rec *)d_recs; p.wg_first = d_wg_first; p.nrec = nrec; p.avgw = 0;
     const bool split = use_split(m, mode);
     p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
-    p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0;
+    p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0; p.stream = m->d_stream;
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
     if (split && split2_applies(m)) {
         const int half_bytes = (int)dgrp_align_up((int64_t)gru_tile_carve(m, p, mode, s, true, DGRP_SPLIT2_PAD, 74 * 1024), 256);
@@ -1234,6 +1235,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, (m->NW > 4 ? 144 : 72) * 1024);
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T,
                  gru_lds_seq(p.Tp));
+    if (split && m->d_stream) return dgrp_stream_launch(p, m->cell, m->NW, total_groups, lds, stream);
     if (split) {
         switch (m->NW) {
         case 1: return launch_split<1>(p, total_groups, lds, stream);

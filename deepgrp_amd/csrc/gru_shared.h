@@ -45,6 +45,8 @@ struct gru_params {
     const uint4 *pack16;
     const float *xtab;
     int xtab_off;
+    // rnn_split_stream_kernel only (rnn_stream.hip): hi and lo recurrent fragments in consumption order, [NW][KS][2 G][64]
+    const uint4 *stream;
 };
 
 // The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
@@ -338,4 +340,21 @@ __device__ __forceinline__ void split_hi_lo4(const float h[4], uint2 &hv, uint2 
     hv = split_pack4(r);
     split_residual4(r, hv);
     lv = split_pack4(r);
+}
+
+// LSTM cell update of one (row, unit) for the split-operand kernel, every a*b+c an explicit fma and nothing left to contract, so
+// that the MODE instantiations of a kernel (merged output / window probabilities) round identically.  Accumulators arrive in the
+// exp2 domain: sigmoid(x) = 1/(1 + 2^a), tanh(x) = 1 - 2/(1 + 2^a).   c' = f c + i tanh(z_c);  h' = o tanh(c')
+__device__ __forceinline__ void split_lstm_cell(float ai, float af, float ac, float ao, float &c, float &h)
+{
+#pragma clang fp contract(off)
+    const float ig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ai));
+    const float fg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(af));
+    const float tc = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ac)), 1.0f);
+    const float it = ig * tc;
+    c = __builtin_fmaf(fg, c, it);
+    const float og = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(ao));
+    const float e2 = __builtin_amdgcn_exp2f(2.8853900817779268f * c);
+    const float th = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e2), 1.0f);
+    h = og * th;
 }

@@ -118,9 +118,10 @@ class DeviceModel:
 
     @property
     def supports_split(self) -> bool:
-        """The split-operand fused kernel (fp16 hi+lo pairs, fp32-grade pre-activations) covers this model (with
-        attention: its recurrent pre-pass)."""
-        return self.rnn == "GRU" and self.units <= 128
+        """A split-operand fused kernel (fp16 hi+lo pairs, fp32-grade pre-activations) covers this model (with attention: its
+        recurrent pre-pass) -- every model: GRU up to 128 units has the resident-weight kernels, larger GRUs and the LSTM cell
+        the streamed one (rnn_stream.hip)."""
+        return True
 
     def set_precision(self, level: int) -> None:
         """dgrp_model_set_precision: 0 = fp16 operands (default), 1 = split operands, for every later call."""

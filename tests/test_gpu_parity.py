@@ -136,10 +136,11 @@ def test_forward_windows_vs_oracle(dev, orc, u, T, attention, gain, s, nw):
     n = (nw + 2) * s + T
     idx = _seq_idx(rng, n)
     want = orc.nn_forward(idx, w, s, 2, nw, np.float64)
-    # both fused kernels: fp16 operands (the fast mode; the default for models without a split kernel) to 1e-3, split
-    # operands (the default where it exists) to fp32 rounding
+    # both fused kernels of every model: fp16 operands (`--fast`) to 1e-3, split operands (the default: resident-weight kernels up
+    # to 128 units, the streamed kernel of rnn_stream.hip beyond) to fp32 rounding
     # (with attention avg[t] still crosses to the second kernel as fp16: 1e-5-level, not amplified by the recurrence)
-    for level, tol in ((0, 1e-3),) + (((1, 3e-4 if attention else 1e-5),) if dm.supports_split else ()):
+    assert dm.supports_split and dm.kernel_flags & 2                 # split operands are the default of every model
+    for level, tol in ((0, 1e-3), (1, 3e-4 if attention else 1e-5)):
         dm.set_precision(level)
         assert bool(dm.kernel_flags & 2) == bool(level)
         got = dm.forward_windows(_t(idx, dev), s, 2, nw).cpu().numpy()
@@ -147,10 +148,6 @@ def test_forward_windows_vs_oracle(dev, orc, u, T, attention, gain, s, nw):
         print(f"u={u} T={T} att={attention} gain={gain} level={level}: max |dp| = {err:.2e}")
         assert err < tol
         np.testing.assert_allclose(got.sum(axis=2), 1.0, atol=1e-5)
-    if not dm.supports_split:
-        from deepgrp_amd._lib import DgrpError
-        with pytest.raises(DgrpError, match="split-operand kernel covers"):
-            dm.set_precision(1)
     dm.close()
 
 
@@ -204,10 +201,14 @@ def test_lstm_forward_vs_oracle(dev, orc, u, T, gain, s, nw):
     n = (nw + 2) * s + T
     idx = _seq_idx(rng, n)
     want = orc.lstm_forward(idx, w, s, 2, nw, np.float64)
-    got = dm.forward_windows(_t(idx, dev), s, 2, nw).cpu().numpy()
-    err = np.abs(got - want).max()
-    print(f"LSTM u={u} T={T} gain={gain}: max |dp| = {err:.2e}")
-    assert err < 1e-3
+    assert dm.supports_split and dm.kernel_flags & 2                 # the streamed split-operand kernel is the LSTM's default
+    for level, tol in ((1, 1e-5), (0, 1e-3)):
+        dm.set_precision(level)
+        got = dm.forward_windows(_t(idx, dev), s, 2, nw).cpu().numpy()
+        err = np.abs(got - want).max()
+        print(f"LSTM u={u} T={T} gain={gain} level={level}: max |dp| = {err:.2e}")
+        assert err < tol
+    dm.set_precision(1)
     # fused merge == get_max of the same probabilities, incl. the short-batch placement
     nwin = orc.window_count(n, T, s)
     probs = dm.forward_windows(_t(idx, dev), s, 0, nwin).cpu().numpy()
