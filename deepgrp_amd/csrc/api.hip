@@ -497,12 +497,13 @@ DGRP_EXPORT int dgrp_model_set_precision(dgrp_model *m, int level)
     return DGRP_OK;
 }
 
-// attention keeps avg[t] (fp16 [nw,T,UP]) and the avg half of the logits (fp32 [nw,T,C]) between kernels
+// attention keeps avg[t] ([nw,T,UP]: fp32 behind the split-operand pre-pass, fp16 behind the fp16-operand one -- sized for fp32, the
+// level can change between the query and the call) and the avg half of the logits (fp32 [nw,T,C]) between kernels
 DGRP_EXPORT int64_t dgrp_forward_workspace_bytes(const dgrp_model *m, int64_t nw)
 {
     if (!m || nw < 0) return 0;
     if (!m->attention) return 256;
-    return dgrp_align_up(nw * m->T * (int64_t)m->UP * 2, 256) + dgrp_align_up(nw * m->T * (int64_t)m->C * 4, 256);
+    return dgrp_align_up(nw * m->T * (int64_t)m->UP * 4, 256) + dgrp_align_up(nw * m->T * (int64_t)m->C * 4, 256);
 }
 
 static int forward_common(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch, int64_t w0,
@@ -528,7 +529,7 @@ static int forward_common(const dgrp_model *m, const uint8_t *d_idx, int64_t n, 
         return DGRP_ENOMEM;
     }
     void *avg = d_work;
-    float *pl = (float *)((char *)d_work + dgrp_align_up(nw * m->T * (int64_t)m->UP * 2, 256));
+    float *pl = (float *)((char *)d_work + dgrp_align_up(nw * m->T * (int64_t)m->UP * 4, 256));
     int rc = dgrp_gru_launch(m, d_idx, n, s, place, w0, nw, 2, pl, avg, stream);
     if (rc) return rc;
     return dgrp_attention_launch(m, s, place, w0, nw, merge, n, avg, pl, d_out, stream);
@@ -552,9 +553,11 @@ DGRP_EXPORT int dgrp_forward_merge(const dgrp_model *m, const uint8_t *d_idx, in
 static int64_t record_window_chunk(const dgrp_model *m)
 {
     if (!m->attention) return 1ll << 20;
-    // keep the avg[t] spill of one launch below ~2 GiB (16-window granularity of the kernels)
-    const int64_t per = (int64_t)m->T * ((int64_t)m->UP * 2 + (int64_t)m->C * 4);
-    int64_t c = ((2ll << 30) / per) / 16 * 16;
+    // keep the avg[t] spill of one launch below ~4 GiB, in whole rounds of workgroups where possible: 4096 windows = 256 CUs x 16
+    // windows (a launch of 4112 windows costs a large model two rounds for the work of one)
+    const int64_t per = (int64_t)m->T * ((int64_t)m->UP * 4 + (int64_t)m->C * 4);
+    int64_t c = (4ll << 30) / per;
+    c = c >= 4096 ? c / 4096 * 4096 : c / 16 * 16;
     if (c < 16) c = 16;
     return c < (1ll << 20) ? c : (1ll << 20);
 }
@@ -665,7 +668,7 @@ static batch_layout batch_carve(const dgrp_model *m, int64_t nrec, int64_t total
     l.post_bytes = std::max<int64_t>(std::max<int64_t>(dgrp_mss_batch_workspace_bytes(total_rows, nrec), dgrp_segments_workspace_bytes(total_rows)), 4096);
     l.post = take(l.post_bytes);
     // attention: avg[t] of every window (fp16) and the avg half of the logits
-    l.avg = take(m->attention ? total_windows * m->T * (int64_t)m->UP * 2 : 0);
+    l.avg = take(m->attention ? total_windows * m->T * (int64_t)m->UP * 4 : 0);
     l.pl = take(m->attention ? total_windows * m->T * (int64_t)m->C * 4 : 0);
     l.bytes = p;
     return l;

@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params 
         if (MODE == 2 && (lane & 15) < nvalid) {
             // attention: keep avg[t] (fp16: it is an fp16 MFMA operand everywhere else too) for the second kernel
             const half8 av = (a0 + a1) * (_Float16)0.5f;
-            *reinterpret_cast<half8 *>(p.avg + ((wg_w + (lane & 15) - p.w0 + p.avgw) * (int64_t)T + tt) * UP + 32 * wave + 8 * (lane >> 4)) = av;
+            *reinterpret_cast<half8 *>(reinterpret_cast<_Float16 *>(p.avg) + ((wg_w + (lane & 15) - p.w0 + p.avgw) * (int64_t)T + tt) * UP + 32 * wave + 8 * (lane >> 4)) = av;
         }
         f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, zero4, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(64 * NW, 2) lstm_fused_kernel(const gru_params
 //   a = softmax_t(e);  ctx = sum_t a[t] avg[t];  logits[t] = ctx.W_top + (avg[t].W_bot + b)
 // ------------------------------------------------------------------------------------------
 struct att_params {
-    const _Float16 *avg; // [nw, T, UP] fp16
+    const void *avg;     // [nw, T, UP] fp16, or fp32 behind a split-operand pre-pass (the kernels' AT)
     const float *pl;     // [nw, T, C]  avg[t].W_bot + b  from the GRU kernel
     const float *scale;  // [UP]
     const float *wtop;   // [UP, 16]
@@ -692,12 +692,13 @@ __device__ __forceinline__ int64_t att_window_row(const att_params &p, int64_t w
 // (running max / sum, context rescaled per tile), the context update runs with thread <-> unit.
 #define ATT_TT 64
 #define ATT_WPB 16                                       // windows per workgroup of the wave kernel below
+template <typename AT>
 __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int T = p.T, UP = p.UP, C = p.C;
     const int TS = UP + 8;                                   // padded tile row (halves): conflict-free column walks
-    _Float16 *tile = reinterpret_cast<_Float16 *>(smem);     // [ATT_TT][TS]
+    AT *tile = reinterpret_cast<AT *>(smem);                  // [ATT_TT][TS]
     float *q = reinterpret_cast<float *>(tile + ATT_TT * TS);   // [UP]
     float *sc = q + UP;                                       // [UP] scale
     float *ctx = sc + UP;                                     // [UP]
@@ -707,7 +708,7 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
     float *cl = red + 8;                                      // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t wl = blockIdx.x;
-    const _Float16 *avg = p.avg + wl * (int64_t)T * UP;
+    const AT *avg = reinterpret_cast<const AT *>(p.avg) + wl * (int64_t)T * UP;
 
     for (int k = tid; k < UP; k += 256) {
         q[k] = (float)avg[(int64_t)(T - 1) * UP + k];         // Average of the two final states = avg[T-1]
@@ -719,18 +720,19 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
     for (int t0 = 0; t0 < T; t0 += ATT_TT) {
         const int nt = min(ATT_TT, T - t0);
         __syncthreads();                                      // previous tile fully consumed (and q/sc/ctx initialised)
-        // stage [nt][UP] halves: 16-byte chunks, coalesced
-        const int chunks_per_row = UP / 8;
+        // stage [nt][UP] elements: 16-byte chunks, coalesced
+        constexpr int EPC = 16 / sizeof(AT);                  // elements per chunk
+        const int chunks_per_row = UP / EPC;
         for (int i = tid; i < nt * chunks_per_row; i += 256) {
             const int r = i / chunks_per_row, c8 = i - r * chunks_per_row;
-            *reinterpret_cast<uint4 *>(tile + r * TS + c8 * 8) =
-                *reinterpret_cast<const uint4 *>(avg + (int64_t)(t0 + r) * UP + c8 * 8);
+            *reinterpret_cast<uint4 *>(tile + r * TS + c8 * EPC) =
+                *reinterpret_cast<const uint4 *>(avg + (int64_t)(t0 + r) * UP + c8 * EPC);
         }
         __syncthreads();
         // scores: lane <-> t, wave <-> quarter of the units
         float e = 0.0f;
         if (lane < nt) {
-            const _Float16 *row = tile + lane * TS + wave * kq;
+            const AT *row = tile + lane * TS + wave * kq;
             const float *qq = q + wave * kq, *ss = sc + wave * kq;
             for (int k = 0; k < kq; ++k) e += ss[k] * fast_tanh(qq[k] + (float)row[k]);
         }
@@ -815,12 +817,22 @@ __device__ __forceinline__ float wave_allsum(float x)
     return (a + b) + (c + d);
 }
 
-template <int UP, int CM>
+// element k of a row held as 16-byte chunks (fp16: 8 per chunk, fp32: 4)
+typedef unsigned att_chunk __attribute__((ext_vector_type(4)));      // 16 bytes as a register vector (HIP's uint4 is a struct)
+template <typename AT, int N>
+__device__ __forceinline__ float att_elem(const att_chunk (&row)[N], int k)
+{
+    if constexpr (sizeof(AT) == 2) return (float)__builtin_bit_cast(half8, row[k / 8])[k % 8];
+    else return __builtin_bit_cast(f32x4, row[k / 4])[k % 4];
+}
+
+template <int UP, int CM, typename AT>
 __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params p)
 {
     constexpr int CT = UP <= 64 ? 64 : 128;                  // context registers per lane (butterfly width)
+    constexpr int EPC = 16 / sizeof(AT);                     // elements per 16-byte chunk
     __shared__ __attribute__((aligned(16))) float qs[4][UP][2];   // per wave: {c*q[k], -2*scale[k]}
-    __shared__ __attribute__((aligned(16))) _Float16 tile[4][64][UP + 8];
+    __shared__ __attribute__((aligned(16))) AT tile[4][64][UP + EPC];
     extern __shared__ __attribute__((aligned(16))) unsigned char att_dyn[];
     unsigned *obuf = reinterpret_cast<unsigned *>(att_dyn);  // merge: max image of the rows the 16 windows cover
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -838,7 +850,7 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
     constexpr float C2 = 2.8853900817779268f;                // 2 log2 e
   for (int wi = wave; wi < nvalid; wi += 4) {
     const int64_t wl = wg0 + wi;
-    const _Float16 *avg = p.avg + wl * (int64_t)T * UP;
+    const AT *avg = reinterpret_cast<const AT *>(p.avg) + wl * (int64_t)T * UP;
     float ssum = 0.0f;
     for (int k = lane; k < UP; k += 64) {
         const float sc = p.scale[k];
@@ -854,17 +866,17 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
     // a tile of 64 steps is fetched with fully coalesced 16-byte loads (1 KiB per wave instruction; a lane reading
     // its own 2*UP-byte row would touch 64 cache lines per instruction and thrash the 16 KiB L1), one tile ahead,
     // and turned into row-per-lane through the wave's private LDS tile (pitch UP + 8 halves: conflict-free both ways)
-    constexpr int CPR = UP / 8, TP = UP + 8;                 // 16-byte chunks per row, LDS row pitch
-    _Float16 *mytile = &tile[wave][0][0];
-    half8 nxt[CPR];
+    constexpr int CPR = UP / EPC, TP = UP + EPC;             // 16-byte chunks per row, LDS row pitch
+    AT *mytile = &tile[wave][0][0];
+    att_chunk nxt[CPR];
     auto fetch = [&](int t0) {
 #pragma unroll
         for (int j = 0; j < CPR; ++j) {
             const int c = j * 64 + lane, r = c / CPR;
-            nxt[j] = t0 + r < T ? *reinterpret_cast<const half8 *>(avg + (int64_t)t0 * UP + (int64_t)c * 8) : half8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+            nxt[j] = t0 + r < T ? *reinterpret_cast<const att_chunk *>(avg + (int64_t)t0 * UP + (int64_t)c * EPC) : att_chunk{ 0u, 0u, 0u, 0u };
         }
     };
-    constexpr bool AHEAD = UP <= 64;                         // beyond 64 units the registers for a tile in flight are gone
+    constexpr bool AHEAD = UP * sizeof(AT) <= 128;           // beyond 64 fp16 / 32 fp32 units the registers for a tile in flight are gone
     if (AHEAD) fetch(0);
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
@@ -873,12 +885,12 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
 #pragma unroll
         for (int j = 0; j < CPR; ++j) {
             const int c = j * 64 + lane;
-            *reinterpret_cast<half8 *>(mytile + (c / CPR) * TP + (c % CPR) * 8) = nxt[j];
+            *reinterpret_cast<att_chunk *>(mytile + (c / CPR) * TP + (c % CPR) * EPC) = nxt[j];
         }
         if (AHEAD && t0 + 64 < T) fetch(t0 + 64);
-        half8 row[CPR];
+        att_chunk row[CPR];
 #pragma unroll
-        for (int j = 0; j < CPR; ++j) row[j] = *reinterpret_cast<const half8 *>(mytile + lane * TP + j * 8);
+        for (int j = 0; j < CPR; ++j) row[j] = *reinterpret_cast<const att_chunk *>(mytile + lane * TP + j * EPC);
         f32x2 acc = { 0.0f, 0.0f };
         // (the offset is laundered so that the 2 UP loop-invariant LDS values are re-read per tile instead of
         // living in registers for the whole kernel)
@@ -893,7 +905,7 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = k0 + 2 * i;
-                const f32x2 a = { (float)row[k / 8][k % 8], (float)row[k / 8][k % 8 + 1] };
+                const f32x2 a = { att_elem<AT>(row, k), att_elem<AT>(row, k + 1) };
                 const f32x2 x = a * C2 + f32x2{ qv[i][0], qv[i][2] };
                 const f32x2 r = rcp1p_exp2_pair(x.x, x.y);
                 acc = r * f32x2{ qv[i][1], qv[i][3] } + acc;
@@ -909,7 +921,7 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
         for (int j = 0; j < CPR; ++j) asm volatile("" : "+v"(row[j]));      // convert again rather than keep UP floats alive
 #pragma unroll
         for (int k = 0; k < UP; k += 2) {
-            const f32x2 a = { (float)row[k / 8][k % 8], (float)row[k / 8][k % 8 + 1] };
+            const f32x2 a = { att_elem<AT>(row, k), att_elem<AT>(row, k + 1) };
             const f32x2 c = f32x2{ ctx[k], ctx[k + 1] } * alpha + a * pt;
             ctx[k] = c.x; ctx[k + 1] = c.y;
         }
@@ -1126,7 +1138,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     dgrp_timer_scope timed(stream, nw);                             // bench.py: HIP events around the launch (no-op unless enabled)
     gru_params p;
     p.idx = d_idx; p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
-    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = (_Float16 *)d_avg;
+    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = d_avg; p.avg_f32 = m->precision == 1 ? 1 : 0;
     p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = mode;
     p.Tp = (int)dgrp_align_up(m->T, 16);
     p.stamps = nullptr;
@@ -1216,7 +1228,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     DGRP_REQUIRE(m->NW <= 8 && (mode == 0 || (mode == 2 && m->cell == 0)), "dgrp_gru_launch_batch: mode 0, or the GRU attention pre-pass");
     gru_params p;
     p.idx = d_idx; p.n = 0; p.s = s; p.w0 = 0; p.nw = 0; p.place = dgrp_placement{ 0, 0 };
-    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = (_Float16 *)d_avg;
+    p.pack = m->d_pack; p.ffb = m->d_ffb; p.out = d_out; p.avg = d_avg; p.avg_f32 = m->precision == 1 ? 1 : 0;
     p.T = m->T; p.C = m->C; p.nfrag = m->nfrag; p.mode = mode;
     p.Tp = (int)dgrp_align_up(m->T, 16);
     p.stamps = nullptr;
@@ -1271,41 +1283,55 @@ int dgrp_attention_launch_recs(const dgrp_model *m, int64_t s, dgrp_placement pl
 {
     if (nw <= 0) return DGRP_OK;
     att_params p;
-    p.avg = (const _Float16 *)d_avg; p.pl = d_pl; p.scale = m->d_scale; p.wtop = m->d_wtop; p.out = d_out;
+    p.avg = d_avg; p.pl = d_pl; p.scale = m->d_scale; p.wtop = m->d_wtop; p.out = d_out;
     p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
     p.T = m->T; p.C = m->C; p.UP = m->UP; p.merge = merge;
     p.recs = (const gru_rec *)d_recs; p.nrec = nrec;
-    const size_t lds = (size_t)ATT_TT * (m->UP + 8) * 2 + (size_t)(3 * m->UP + 4 * ATT_TT + ATT_TT + 8 + 16) * sizeof(float);
+    // element type of the avg[t] spill: fp32 behind a split-operand pre-pass (the level the model is set to), else fp16
+    const bool f32 = m->precision == 1;
+    const int esz = f32 ? 4 : 2;
+    const size_t lds = (size_t)ATT_TT * (m->UP + 8) * esz + (size_t)(3 * m->UP + 4 * ATT_TT + ATT_TT + 8 + 16) * sizeof(float);
     DGRP_REQUIRE(nw < (1ll << 31), "too many windows in one launch");
     p.ospan = 0;
     const int64_t want = (ATT_WPB - 1) * s + m->T;
     const unsigned grid = (unsigned)((nw + ATT_WPB - 1) / ATT_WPB);
     if (m->UP <= 64 && !getenv("DGRP_ATT_TILE")) {
         // one wave per window; beyond 64 units its per-lane context (UP registers) no longer fits beside the row
-        const int stat = 4 * m->UP * 2 * 4 + 4 * 64 * (m->UP + 8) * 2;           // qs + tiles (static LDS of the kernel)
+        const int stat = 4 * m->UP * 2 * 4 + 4 * 64 * (m->UP + 16 / esz) * esz;  // qs + tiles (static LDS of the kernel)
         if (merge) {
-            const int64_t cap = (78 * 1024 - stat) / (m->C * 4);                 // two workgroups per CU
+            const int64_t budget = stat <= 40 * 1024 ? 78 * 1024 : 156 * 1024;   // two workgroups per CU where the tiles leave room
+            const int64_t cap = (budget - stat) / (m->C * 4);
             p.ospan = (int)(want < cap ? want : cap);
             if (p.ospan < m->T) p.ospan = 0;
         }
         const size_t dyn = (size_t)p.ospan * m->C * 4;
         static bool configured = false;
         if (!configured) {                                   // static + dynamic LDS may use the whole 160 KiB
-            const int d32 = 160 * 1024 - (4 * 32 * 8 + 256 * 40 * 2), d64 = 160 * 1024 - (4 * 64 * 8 + 256 * 72 * 2);
-            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, d32));
-            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<32, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, d32));
-            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, d64));
-            DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, d64));
+#define ATT_CFG(UPv, CMv, ATv) DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<UPv, CMv, ATv>, \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (4 * UPv * 8 + 256 * (UPv + (int)(16 / sizeof(ATv))) * (int)sizeof(ATv))))
+            ATT_CFG(32, 8, _Float16); ATT_CFG(32, 16, _Float16); ATT_CFG(64, 8, _Float16); ATT_CFG(64, 16, _Float16);
+            ATT_CFG(32, 8, float); ATT_CFG(32, 16, float); ATT_CFG(64, 8, float); ATT_CFG(64, 16, float);
+#undef ATT_CFG
             configured = true;
         }
-        if (m->UP == 32 && m->C <= 8) hipLaunchKernelGGL((attention_wave_kernel<32, 8>), dim3(grid), dim3(256), dyn, stream, p);
-        else if (m->UP == 32) hipLaunchKernelGGL((attention_wave_kernel<32, 16>), dim3(grid), dim3(256), dyn, stream, p);
-        else if (m->C <= 8) hipLaunchKernelGGL((attention_wave_kernel<64, 8>), dim3(grid), dim3(256), dyn, stream, p);
-        else hipLaunchKernelGGL((attention_wave_kernel<64, 16>), dim3(grid), dim3(256), dyn, stream, p);
+#define ATT_GO(UPv, CMv) do { if (f32) hipLaunchKernelGGL((attention_wave_kernel<UPv, CMv, float>), dim3(grid), dim3(256), dyn, stream, p); \
+                              else hipLaunchKernelGGL((attention_wave_kernel<UPv, CMv, _Float16>), dim3(grid), dim3(256), dyn, stream, p); } while (0)
+        if (m->UP == 32 && m->C <= 8) ATT_GO(32, 8);
+        else if (m->UP == 32) ATT_GO(32, 16);
+        else if (m->C <= 8) ATT_GO(64, 8);
+        else ATT_GO(64, 16);
+#undef ATT_GO
         DGRP_LAUNCH_CHECK();
         return DGRP_OK;
     }
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)nw), dim3(256), lds, stream, p);
+    static bool tile_configured = false;
+    if (!tile_configured) {
+        DGRP_HIP(hipFuncSetAttribute((const void *)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        DGRP_HIP(hipFuncSetAttribute((const void *)attention_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        tile_configured = true;
+    }
+    if (f32) hipLaunchKernelGGL(attention_kernel<float>, dim3((unsigned)nw), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL(attention_kernel<_Float16>, dim3((unsigned)nw), dim3(256), lds, stream, p);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
 }

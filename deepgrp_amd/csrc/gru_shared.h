@@ -25,7 +25,8 @@ struct gru_params {
     const uint4 *pack;
     const float *ffb;
     float *out;           // mode 0: merged [n, C]; mode 1: probs [nw, T, C]; mode 2: logits part [nw, T, C]
-    _Float16 *avg;        // mode 2: [nw, T, UP] fp16
+    void *avg;            // mode 2: [nw, T, UP], fp16 (fp16-operand kernels) or fp32 (split-operand kernels: avg_f32)
+    int avg_f32;
     int T, C, nfrag, mode;
     int Tp;               // T rounded up to 16 (row pitch of the staged sequences)
     int ospan;            // rows of the LDS output image (mode 0), 0 = none
@@ -253,15 +254,30 @@ __device__ __forceinline__ void flush_image(const gru_params &p, const wg_ctx &c
 #endif
 
 // attention pre-pass of the split-operand kernels: avg[t] of this wave's 32 units for window (lane & 15), summed from the
-// hi and lo halves of both strands and stored as fp16 like the fp16-operand kernel does (the second kernel's operand)
+// hi and lo halves of both strands (the second kernel's operand)
 __device__ __forceinline__ void split_avg_store(const gru_params &p, int64_t wg_w, int tt, int UP, int wave, half8 a0, half8 a1,
                                                 half8 l0, half8 l1)
 {
     const int lane = threadIdx.x & 63;
+    const int64_t at = ((wg_w + (lane & 15) - p.w0 + p.avgw) * (int64_t)p.T + tt) * UP + 32 * wave + 8 * (lane >> 4);
+    if (p.avg_f32) {
+        // fp32 spill: avg = ((f_hi + f_lo) + (r_hi + r_lo)) / 2 in float, so that the attention kernel sees what the recurrence computed
+        // to fp32 rounding (an fp16 spill costs the second kernel 1e-4 in the class probabilities)
+        float *dst = reinterpret_cast<float *>(p.avg) + at;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = 0.5f * (((float)a0[j] + (float)l0[j]) + ((float)a1[j] + (float)l1[j]));
+            v1[j] = 0.5f * (((float)a0[4 + j] + (float)l0[4 + j]) + ((float)a1[4 + j] + (float)l1[4 + j]));
+        }
+        *reinterpret_cast<f32x4 *>(dst) = v0;
+        *reinterpret_cast<f32x4 *>(dst + 4) = v1;
+        return;
+    }
     // packed fp16 arithmetic (the halvings are exact; one rounding per add): a quarter of the instructions of a float detour
     const _Float16 hf = (_Float16)0.5f;
     const half8 av = (a0 * hf + a1 * hf) + (l0 + l1) * hf;
-    *reinterpret_cast<half8 *>(p.avg + ((wg_w + (lane & 15) - p.w0 + p.avgw) * (int64_t)p.T + tt) * UP + 32 * wave + 8 * (lane >> 4)) = av;
+    *reinterpret_cast<half8 *>(reinterpret_cast<_Float16 *>(p.avg) + at) = av;
 }
 
 // Gate math of ONE (row, unit) of the split-operand kernels as a chain of single operations, written once so that the

@@ -297,9 +297,9 @@ class ContigPipeline:
             return out
         chunk = self.chunk_windows
         if m.attention:
-            # keep the avg[t] spill of one launch below ~2 GiB
-            per = m.vecsize * (((m.units + 31) // 32) * 32 * 2 + m.classes * 4)
-            chunk = max(16, min(chunk, (2 << 30) // per // 16 * 16))
+            per = m.vecsize * (((m.units + 31) // 32) * 32 * 4 + m.classes * 4)       # avg[t] as fp32 + the avg half of the logits
+            fit = (4 << 30) // per                            # ~4 GiB of spill per launch, whole rounds of workgroups (4096 windows) if possible
+            chunk = max(16, min(chunk, fit // 4096 * 4096 if fit >= 4096 else fit // 16 * 16))
         work = None
         w0 = 0
         while w0 < nwin:

@@ -68,7 +68,7 @@ class RecordRunner:
         cost = 80 * n
         m = self.pipe.model
         if m.attention:
-            cost += len(range(0, n - self._T, self.pipe.step)) * self._T * (self._UP * 2 + m.classes * 4)
+            cost += len(range(0, n - self._T, self.pipe.step)) * self._T * (self._UP * 4 + m.classes * 4)
         return cost
 
     def work_items(self, records: Iterable[Tuple[object, object]]) -> Iterator[Tuple[object, object]]:
