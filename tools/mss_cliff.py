@@ -22,7 +22,7 @@ def dirichlet_scores(alpha):
 
 
 styles = {
-    "dirichlet(0.3): upward drift, L ~ 1e7 next to 2^-40 quanta": lambda: dirichlet_scores(0.3),
+    "dirichlet(0.3) probabilities: downward drift (class 0 scores -10 t), L ~ -1e7 next to 2^-40 quanta": lambda: dirichlet_scores(0.3),
     "normal(+0.3, 1): upward drift, inexact": lambda: (rng.normal(0.3, 1, n), rng.integers(0, 5, n)),
     "normal(0, 5): no drift": lambda: (rng.normal(0, 5, n), rng.integers(0, 5, n)),
     "normal(-0.3, 1): downward drift (a flush at almost every run)": lambda: (rng.normal(-0.3, 1, n), rng.integers(0, 5, n)),
