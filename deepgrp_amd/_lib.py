@@ -30,6 +30,10 @@ _SIGNATURES = {
     "dgrp_fasta_encode": (cint, [vp, i64, vp, C.POINTER(i64), vp, i64, vp]),
     "dgrp_fasta_batch_workspace_bytes": (i64, [i64, i64]),
     "dgrp_fasta_encode_batch": (cint, [vp, i64, vp, vp, vp, vp, vp, i64, vp]),
+    "dgrp_fasta_chunks_workspace_bytes": (i64, [i64]),
+    "dgrp_fasta_chunks": (cint, [vp, i64, i64, vp, vp, C.POINTER(i64), vp, i64, vp]),
+    "dgrp_format_rows_bound": (i64, [i64, i64]),
+    "dgrp_format_rows": (cint, [vp, vp, i64, cint, vp, i64, vp, i64, C.POINTER(i64)]),
     "dgrp_window_count": (i64, [i64, i64, i64]),
     "dgrp_windows_onehot": (cint, [vp, i64, i64, i64, i64, i64, cint, vp, vp]),
     "dgrp_model_create": (cint, [C.POINTER(vp), cint, cint, cint, cint, vp, vp, vp, vp, vp, vp]),

@@ -4,6 +4,8 @@
 // reference's numpy / C code rounds.
 #include "dgrp_common.h"
 #include <vector>
+#include <algorithm>
+#include <string.h>
 
 #include <math.h>
 
@@ -622,6 +624,152 @@ DGRP_EXPORT int dgrp_fasta_encode_batch(const uint8_t *d_raw, int64_t nrec, cons
         if (g[2] == 0) { info[2] = tot; info[3] = -tot; }
         else { info[2] = (int64_t)g[1]; info[3] = (int64_t)g[2] - (int64_t)g[1]; }
     }
+    return DGRP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// A1  where the records of a FASTA file start (_read_multi_fasta, deepgrp/__main__.py:31-41: a line whose first character is '>'
+// opens a record), found on the uploaded file instead of by host passes over it.  A CHUNK starts at byte 0 and at every '>' that
+// directly follows a line feed.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fasta_gt_kernel(const uint8_t *__restrict__ raw, int64_t n, int64_t cap,
+                                                       unsigned long long *__restrict__ count, int64_t *__restrict__ list)
+{
+    // 16 bytes per thread (the buffer is a fresh allocation: 16-byte aligned); '>' is rare, so the append is an atomic
+    const int64_t nvec = n / 16;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v <= nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p0 = v * 16;
+        union { uint4 q; uint8_t b[16]; } u;
+        uint8_t *b = u.b;
+        int m = 16;
+        if (v < nvec) {
+            u.q = *(const uint4 *)(raw + p0);
+        } else {
+            m = (int)(n - p0);
+            for (int j = 0; j < m; ++j) b[j] = raw[p0 + j];
+        }
+        bool any = false;
+        for (int j = 0; j < m; ++j) any = any || b[j] == '>';
+        if (!any) continue;
+        uint8_t prev = p0 > 0 ? raw[p0 - 1] : 0;
+        for (int j = 0; j < m; ++j) {
+            if (b[j] == '>' && prev == 10 ) {
+                const unsigned long long at = atomicAdd(count, 1ull);
+                if ((int64_t)at < cap) list[at] = p0 + j;
+            }
+            prev = b[j];
+        }
+    }
+}
+
+// one thread per chunk: the first line feed at or after its start (n if there is none)
+__global__ void __launch_bounds__(256) fasta_firstlf_kernel(const uint8_t *__restrict__ raw, int64_t n, const int64_t *__restrict__ start,
+                                                            int64_t nchunks, int64_t *__restrict__ first_lf)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nchunks) return;
+    const int64_t stop = c + 1 < nchunks ? start[c + 1] : n;       // a later chunk starts behind a line feed: the search ends before it
+    int64_t p = start[c];
+    while (p < stop && raw[p] != 10) ++p;
+    first_lf[c] = p < stop ? p : n;
+}
+
+DGRP_EXPORT int64_t dgrp_fasta_chunks_workspace_bytes(int64_t cap)
+{
+    if (cap < 0) return 0;
+    return 256 + dgrp_align_up((cap + 1) * 8, 256) * 2;
+}
+
+// h_start[0] = 0 and the '>' positions in ascending order, h_first_lf[i] as fasta_firstlf_kernel defines it; *n_chunks is the number
+// of chunks found -- if it exceeds cap nothing else is valid and the caller repeats the call with cap >= *n_chunks.  Synchronous.
+DGRP_EXPORT int dgrp_fasta_chunks(const uint8_t *d_raw, int64_t nbytes, int64_t cap, int64_t *h_start, int64_t *h_first_lf,
+                                  int64_t *n_chunks, void *d_work, int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(nbytes >= 0 && cap >= 1 && h_start && h_first_lf && n_chunks, "dgrp_fasta_chunks: bad arguments");
+    if (nbytes == 0) { *n_chunks = 0; return DGRP_OK; }
+    DGRP_REQUIRE(d_raw && d_work, "dgrp_fasta_chunks: NULL pointer");
+    DGRP_REQUIRE(((uintptr_t)d_raw & 15) == 0, "dgrp_fasta_chunks: d_raw must be 16-byte aligned");
+    if (work_bytes < dgrp_fasta_chunks_workspace_bytes(cap)) {
+        dgrp_set_error("dgrp_fasta_chunks: workspace too small");
+        return DGRP_ENOMEM;
+    }
+    unsigned long long *d_count = (unsigned long long *)d_work;
+    int64_t *d_list = (int64_t *)((unsigned char *)d_work + 256);
+    int64_t *d_lf = (int64_t *)((unsigned char *)d_list + dgrp_align_up((cap + 1) * 8, 256));
+    DGRP_HIP(hipMemsetAsync(d_count, 0, 8, stream));
+    const int64_t nvec = nbytes / 16 + 1;
+    const unsigned grid = (unsigned)(nvec + 255) / 256 > 16384u ? 16384u : (unsigned)((nvec + 255) / 256);
+    hipLaunchKernelGGL(fasta_gt_kernel, dim3(grid), dim3(256), 0, stream, d_raw, nbytes, cap - 1, d_count, d_list + 1);
+    DGRP_LAUNCH_CHECK();
+    unsigned long long found = 0;
+    DGRP_HIP(hipMemcpyAsync(&found, d_count, 8, hipMemcpyDeviceToHost, stream));
+    DGRP_HIP(hipStreamSynchronize(stream));
+    *n_chunks = (int64_t)found + 1;
+    if (*n_chunks > cap) return DGRP_OK;
+    h_start[0] = 0;
+    if (found) {
+        DGRP_HIP(hipMemcpyAsync(h_start + 1, d_list + 1, found * 8, hipMemcpyDeviceToHost, stream));
+        DGRP_HIP(hipStreamSynchronize(stream));
+        std::sort(h_start + 1, h_start + 1 + found);
+    }
+    DGRP_HIP(hipMemcpyAsync(d_list, h_start, (found + 1) * 8, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(fasta_firstlf_kernel, dim3((unsigned)((found + 1 + 255) / 256)), dim3(256), 0, stream, d_raw, nbytes, d_list,
+                       (int64_t)found + 1, d_lf);
+    DGRP_LAUNCH_CHECK();
+    DGRP_HIP(hipMemcpyAsync(h_first_lf, d_lf, (found + 1) * 8, hipMemcpyDeviceToHost, stream));
+    DGRP_HIP(hipStreamSynchronize(stream));
+    return DGRP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// A12  the TSV rows of deepgrp/__main__.py:291-292 as text: "<prefix>start\tend\tlabel\n" per row, prefix = "file\theader\t" of the
+// row's record (row.contig indexes the prefixes when by_contig, else prefix 0).  Host code: 100 000 rows are a few hundred
+// microseconds here and tens of milliseconds as numpy string columns.
+// ------------------------------------------------------------------------------------------
+static inline char *put_int(char *o, long long v)
+{
+    char tmp[24];
+    int k = 0;
+    unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+    do { tmp[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *o++ = '-';
+    while (k) *o++ = tmp[--k];
+    return o;
+}
+
+DGRP_EXPORT int64_t dgrp_format_rows_bound(int64_t nrows, int64_t longest_prefix)
+{
+    if (nrows < 0 || longest_prefix < 0) return 0;
+    return nrows * (longest_prefix + 21 + 21 + 12 + 3) + 1;
+}
+
+DGRP_EXPORT int dgrp_format_rows(const char *prefixes, const int64_t *prefix_off, int64_t nprefix, int by_contig,
+                                 const dgrp_segment *rows, int64_t nrows, char *out, int64_t cap, int64_t *written)
+{
+    DGRP_REQUIRE(nrows >= 0 && nprefix >= 1 && prefixes && prefix_off && written && (nrows == 0 || (rows && out)),
+                 "dgrp_format_rows: bad arguments");
+    int64_t longest = 0;
+    for (int64_t i = 0; i < nprefix; ++i) {
+        DGRP_REQUIRE(prefix_off[i + 1] >= prefix_off[i], "dgrp_format_rows: prefix offsets must ascend");
+        if (prefix_off[i + 1] - prefix_off[i] > longest) longest = prefix_off[i + 1] - prefix_off[i];
+    }
+    if (cap < dgrp_format_rows_bound(nrows, longest)) {
+        dgrp_set_error("dgrp_format_rows: output buffer too small (dgrp_format_rows_bound)");
+        return DGRP_ENOMEM;
+    }
+    char *o = out;
+    for (int64_t r = 0; r < nrows; ++r) {
+        const int64_t c = by_contig ? rows[r].contig : 0;
+        DGRP_REQUIRE(c >= 0 && c < nprefix, "dgrp_format_rows: row %lld names record %lld of %lld", (long long)r, (long long)c, (long long)nprefix);
+        const int64_t len = prefix_off[c + 1] - prefix_off[c];
+        memcpy(o, prefixes + prefix_off[c], (size_t)len);
+        o += len;
+        o = put_int(o, rows[r].start); *o++ = '\t';
+        o = put_int(o, rows[r].end); *o++ = '\t';
+        o = put_int(o, rows[r].label); *o++ = '\n';
+    }
+    *written = o - out;
     return DGRP_OK;
 }
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import io
 import mmap
+import threading
 import os
 from typing import Iterator, List, TextIO, Tuple, Union
 
@@ -124,6 +125,72 @@ class DeviceRecord:
         return self._view
 
 
+RESIDENT_BYTES = int(os.environ.get("DGRP_FASTA_RESIDENT_BYTES", str(32 << 30)))   # files up to here are uploaded whole (HBM: 288 GB)
+_SLAB = 32 << 20
+_UPLOAD: dict = {}
+_UPLOAD_LOCK = threading.Lock()       # one file at a time through the two slabs
+
+
+def _upload_file(path, size: int, dev):
+    """The file's bytes in HBM: read(2) straight into two pinned slabs in turn, each sent by the copy engine while the next is read."""
+    import torch
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _UPLOAD:
+        _UPLOAD[key] = ([torch.empty(_SLAB, dtype=torch.uint8).pin_memory() for _ in range(2)], torch.cuda.Stream(device=dev))
+    slabs, copy = _UPLOAD[key]
+    with _UPLOAD_LOCK:
+        return _upload_through(path, size, dev, slabs, copy)
+
+
+def _upload_through(path, size: int, dev, slabs, copy):
+    import torch
+    views = [b.numpy() for b in slabs]
+    d_file = torch.empty(size, dtype=torch.uint8, device=dev)
+    sent = [None, None]
+    copy.wait_stream(torch.cuda.current_stream())
+    with open(path, "rb", buffering=0) as fh:
+        o = i = 0
+        while o < size:
+            j = i & 1
+            if sent[j] is not None:
+                sent[j].synchronize()                    # the slab's previous content has left
+            k = fh.readinto(views[j][:min(_SLAB, size - o)])
+            if not k:
+                raise OSError(f"{path}: shorter than its size at open ({o} of {size} bytes)")
+            with torch.cuda.stream(copy):
+                d_file[o:o + k].copy_(slabs[j][:k], non_blocking=True)
+                sent[j] = torch.cuda.Event()
+                sent[j].record(copy)
+            o += k
+            i += 1
+    for ev in sent:
+        if ev is not None:
+            ev.synchronize()                             # the slabs are free for the next caller
+    torch.cuda.current_stream().wait_stream(copy)
+    return d_file
+
+
+def _device_chunks(L, d_file, size: int):
+    """(chunk starts, first line feed of each chunk or `size`) of the uploaded file: dgrp_fasta_chunks."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from ._lib import check
+    from .pipeline import stream_ptr
+    cap = 4096
+    while True:
+        wb = L.dgrp_fasta_chunks_workspace_bytes(cap)
+        work = torch.empty(wb, dtype=torch.uint8, device=d_file.device)
+        st, lf, n = np.empty(cap, np.int64), np.empty(cap, np.int64), C.c_int64()
+        check(L.dgrp_fasta_chunks(d_file.data_ptr(), size, cap, st.ctypes.data, lf.ctypes.data, C.byref(n), work.data_ptr(), wb,
+                                  stream_ptr()), "dgrp_fasta_chunks")
+        if n.value <= cap:
+            return st[:n.value], lf[:n.value]
+        cap = n.value
+
+
 def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 256 << 20, group_records: int = 4096):
     """Like read_multi_fasta_file, but plain record bodies are uploaded as raw file bytes and turned
     into class indices on the GPU (dgrp_fasta_encode_batch: line-end removal, upper-casing, N stripping and
@@ -150,20 +217,31 @@ def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 25
         carry_header = ""
         carry_seq: List[str] = []
         try:
-            # chunk table in numpy (a file of 100 000 records would otherwise spend its time in per-record find()s):
-            # chunk starts = file start and every '>' that follows a line feed; end of each chunk's first line
-            blk = 1 << 28                                                      # bounded temporaries on multi-GB files
-            lf_pos = np.concatenate([np.flatnonzero(whole[o:o + blk] == 10) + o for o in range(0, size, blk)] or [np.zeros(0, np.int64)])
-            nxt = lf_pos + 1
-            nxt = nxt[nxt < size]
-            starts_np = np.concatenate([[0], nxt[whole[nxt] == 62], [size]]).astype(np.int64)
-            del nxt
-            k = np.searchsorted(lf_pos, starts_np[:-1])                       # first line feed at or after the chunk start
-            first_lf = np.where(k < lf_pos.size, lf_pos[np.minimum(k, max(lf_pos.size - 1, 0))] if lf_pos.size else size, size)
+            d_file = None
+            if size <= RESIDENT_BYTES:
+                # the whole file goes up once (pinned slabs, the read of slab k+1 overlaps the DMA of slab k) and the chunk
+                # table comes from a device pass over it (dgrp_fasta_chunks): the host touches the header lines only
+                d_file = _upload_file(path, size, dev)
+                st, first_lf = _device_chunks(L, d_file, size)
+                starts_np = np.concatenate([st, [size]]).astype(np.int64)
+                gt_np = np.ones(st.size, bool)
+                gt_np[0] = mm[0] == 62
+            else:
+                # chunk table in numpy (a file of 100 000 records would otherwise spend its time in per-record find()s):
+                # chunk starts = file start and every '>' that follows a line feed; end of each chunk's first line
+                blk = 1 << 28                                                  # bounded temporaries on multi-GB files
+                lf_pos = np.concatenate([np.flatnonzero(whole[o:o + blk] == 10) + o for o in range(0, size, blk)] or [np.zeros(0, np.int64)])
+                nxt = lf_pos + 1
+                nxt = nxt[nxt < size]
+                starts_np = np.concatenate([[0], nxt[whole[nxt] == 62], [size]]).astype(np.int64)
+                del nxt
+                k = np.searchsorted(lf_pos, starts_np[:-1])                   # first line feed at or after the chunk start
+                first_lf = np.where(k < lf_pos.size, lf_pos[np.minimum(k, max(lf_pos.size - 1, 0))] if lf_pos.size else size, size)
+                gt_np = whole[starts_np[:-1]] == 62
+                del lf_pos, k
             head_end_np = np.minimum(first_lf, starts_np[1:])                 # no line feed inside the chunk: header runs to its end
             body0_np = np.where(first_lf < starts_np[1:], first_lf + 1, starts_np[1:])
-            gt_np = whole[starts_np[:-1]] == 62
-            del lf_pos, k, first_lf
+            del first_lf
             starts = starts_np.tolist()
             head_ends, body0_all, gt_all = head_end_np.tolist(), body0_np.tolist(), gt_np.tolist()
             nchunks = len(starts) - 1
@@ -184,7 +262,8 @@ def read_multi_fasta_device(path: Union[str, os.PathLike], group_bytes: int = 25
                 infos = np.zeros((c1 - c0, 4), np.int64)
                 d_idx = None
                 if any(cand):
-                    d_raw = torch.from_numpy(whole[g0:g1]).to(dev)              # numpy view of the mmap: no host copy
+                    # resident file: a view; else the group's bytes go up now (numpy view of the mmap: no host copy)
+                    d_raw = d_file[g0:g1] if d_file is not None else torch.from_numpy(whole[g0:g1]).to(dev)
                     d_idx = torch.empty(g1 - g0, dtype=torch.uint8, device=dev)
                     off = np.array([body0s[i] - g0 for i in range(c1 - c0)], np.int64)
                     ln = np.array([(starts[c0 + i + 1] - body0s[i]) if cand[i] else 0 for i in range(c1 - c0)], np.int64)

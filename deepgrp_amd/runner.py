@@ -22,25 +22,51 @@ BATCH_RECORDS = 4096
 BATCH_BYTES = 4 << 30         # workspace a batch may ask for
 
 
+_STREAMS: dict = {}
+_STREAMS_LOCK = threading.Lock()
+
+
+def _worker_stream(dev: int, i: int):
+    """Stream of worker i on device dev, the same object for every runner of the process: torch's allocator caches blocks per
+    stream, so a fresh stream per run would leave the previous run's workspaces (14 GB for a 250 Mbp record) reserved for good."""
+    with _STREAMS_LOCK:
+        pool = _STREAMS.setdefault(dev, [])
+        while len(pool) <= i:
+            pool.append(torch.cuda.Stream(device=dev))
+        return pool[i]
+
+
+def _format(prefixes: List[bytes], by_contig: bool, rows) -> str:
+    """dgrp_format_rows (host code of the library): one pass over the row records, no per-row Python objects."""
+    import ctypes as C
+
+    from ._lib import check, lib
+    from .pipeline import SEGMENT_DTYPE
+    L = lib()
+    rows = np.ascontiguousarray(rows, dtype=SEGMENT_DTYPE)
+    blob = b"".join(prefixes)
+    off = np.zeros(len(prefixes) + 1, np.int64)
+    np.cumsum([len(p) for p in prefixes], out=off[1:])
+    cap = L.dgrp_format_rows_bound(len(rows), max(len(p) for p in prefixes))
+    out = np.empty(cap, np.uint8)
+    written = C.c_int64()
+    check(L.dgrp_format_rows(blob, off.ctypes.data, len(prefixes), int(by_contig), rows.ctypes.data, len(rows), out.ctypes.data, cap,
+                             C.byref(written)), "dgrp_format_rows")
+    return out[:written.value].tobytes().decode("utf-8", "surrogateescape")
+
+
 def rows_text(filename: str, header: str, rows) -> str:
-    """The TSV rows of one record (__main__.py:291-292), built column-wise: integer -> text and the
-    concatenations are numpy loops, not one str.format per row."""
+    """The TSV rows of one record (__main__.py:291-292)."""
     if len(rows) == 0:
         return ""
-    prefix = "{}\t{}\t".format(filename, header)
-    cols = [rows[name].astype(np.int64).astype("U") for name in ("start", "end", "label")]
-    body = np.char.add(np.char.add(np.char.add(np.char.add(cols[0], "\t"), cols[1]), "\t"), cols[2])
-    return prefix + ("\n" + prefix).join(body.tolist()) + "\n"
+    return _format(["{}\t{}\t".format(filename, header).encode("utf-8", "surrogateescape")], False, rows)
 
 
 def rows_text_batch(filename: str, headers, rows) -> str:
     """The rows of a batch of records (rows["contig"] = index into `headers`), record order = row order."""
     if len(rows) == 0:
         return ""
-    prefixes = np.array(["{}\t{}\t".format(filename, h) for h in headers])[rows["contig"]]
-    cols = [rows[name].astype(np.int64).astype("U") for name in ("start", "end", "label")]
-    body = np.char.add(np.char.add(np.char.add(np.char.add(np.char.add(prefixes, cols[0]), "\t"), cols[1]), "\t"), cols[2])
-    return "\n".join(body.tolist()) + "\n"
+    return _format(["{}\t{}\t".format(filename, h).encode("utf-8", "surrogateescape") for h in headers], True, rows)
 
 
 class RecordRunner:
@@ -114,13 +140,14 @@ class RecordRunner:
         bases in flight are bounded; an exception surfaces where the sequential loop would raise it."""
         dev = torch.cuda.current_device() if torch.cuda.is_available() else None
         local = threading.local()
+        taken = iter(range(self.workers))
 
         def task(item):
             if dev is None:
                 return self.run_item(item)
             if not hasattr(local, "stream"):
                 torch.cuda.set_device(dev)
-                local.stream = torch.cuda.Stream()
+                local.stream = _worker_stream(dev, next(taken))
             with torch.cuda.stream(local.stream):
                 out = self.run_item(item)
                 local.stream.synchronize()

@@ -86,6 +86,15 @@ int64_t dgrp_fasta_batch_workspace_bytes(int64_t nrec, int64_t total_bytes);
 int dgrp_fasta_encode_batch(const uint8_t *d_raw, int64_t nrec, const int64_t *h_off, const int64_t *h_len,
                             uint8_t *d_idx, int64_t *h_info, void *d_work, int64_t work_bytes, void *stream);
 
+/* ---- A1: where the records of an uploaded FASTA file start (_read_multi_fasta, deepgrp/__main__.py:31-41: a line whose first
+ * character is '>' opens a record).  d_raw [nbytes] = the file as it is, 16-byte aligned.  A chunk starts at byte 0 and at every '>'
+ * that directly follows a line feed.  h_start[0..n) ascending chunk starts, h_first_lf[i] = position of the first line feed in chunk i
+ * (nbytes if it has none: the header line runs to the chunk's end).  *n_chunks = chunks found; if it exceeds cap nothing else is
+ * valid: call again with cap >= *n_chunks.  Synchronous.  Replaces host passes over the file bytes (numpy compare + nonzero). */
+int64_t dgrp_fasta_chunks_workspace_bytes(int64_t cap);
+int dgrp_fasta_chunks(const uint8_t *d_raw, int64_t nbytes, int64_t cap, int64_t *h_start, int64_t *h_first_lf,
+                      int64_t *n_chunks, void *d_work, int64_t work_bytes, void *stream);
+
 /* ---- A3: deepgrp.prediction.fetch_validation_batch (deepgrp/prediction.py:14-37)
  * Number of windows len(range(0, n - T, s)). */
 int64_t dgrp_window_count(int64_t n, int64_t T, int64_t s);
@@ -202,6 +211,14 @@ int64_t dgrp_segments_workspace_bytes(int64_t n);
 int dgrp_segments(const int8_t *d_labels, int64_t n, int64_t offset, int32_t contig,
                   dgrp_segment *d_records, int64_t cap, int64_t *d_count, void *d_work,
                   int64_t work_bytes, void *stream);
+
+/* ---- A12: the TSV rows of deepgrp/__main__.py:291-292 as text (host code, host buffers): per row
+ * "<prefix>start\tend\tlabel\n", prefix i = bytes [prefix_off[i], prefix_off[i+1]) of `prefixes` ("file\theader\t" of record i);
+ * a row takes prefix rows[r].contig if by_contig != 0, else prefix 0.  out capacity >= dgrp_format_rows_bound(nrows, longest
+ * prefix); *written = bytes produced. */
+int64_t dgrp_format_rows_bound(int64_t nrows, int64_t longest_prefix);
+int dgrp_format_rows(const char *prefixes, const int64_t *prefix_off, int64_t nprefix, int by_contig,
+                     const dgrp_segment *rows, int64_t nrows, char *out, int64_t cap, int64_t *written);
 
 /* ---- A3-A11 in one call: everything deepgrp/__main__.py:46-83 and :288-292 do for ONE record whose class indices
  * (after N stripping, startpos = offset) are in HBM: windows, forward, max-merge with the reference's placement for

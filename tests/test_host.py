@@ -568,6 +568,31 @@ def test_record_runner_grouping_and_order():
     assert rn.rows_text_batch("f.fa", ["r0", "r1"], rows) == rn.rows_text("f.fa", "r0", rows[:1]) + rn.rows_text("f.fa", "r1", rows[1:])
 
 
+def test_rows_text_is_the_reference_format():
+    """__main__.py:291-292: '\t'.join(str(x) for x in (filename, header, start, end, label)) per row -- dgrp_format_rows (host code
+    of the library) against exactly that, incl. 19-digit coordinates, a non-ASCII header and per-row records of a batch."""
+    from deepgrp_amd import runner as rn
+    from deepgrp_amd.pipeline import SEGMENT_DTYPE
+    rng = np.random.default_rng(3)
+    n = 5000
+    rows = np.zeros(n, SEGMENT_DTYPE)
+    rows["start"] = rng.integers(0, 1 << 62, n) >> rng.integers(0, 62, n)
+    rows["end"] = rows["start"] + rng.integers(1, 1 << 40, n)
+    rows["label"] = rng.integers(1, 5, n)
+    rows["contig"] = rng.integers(0, 3, n)
+    heads = ["chr1 any text", "sp|Q9Ünï|x", "c"]
+    want = "".join("\t".join(str(x) for x in ("a b/f.fa", heads[r["contig"]], r["start"], r["end"], r["label"])) + "\n" for r in rows)
+    assert rn.rows_text_batch("a b/f.fa", heads, rows) == want
+    one = rows[rows["contig"] == 1]
+    assert rn.rows_text("a b/f.fa", heads[1], one) == "".join(
+        "\t".join(str(x) for x in ("a b/f.fa", heads[1], r["start"], r["end"], r["label"])) + "\n" for r in one)
+    assert rn.rows_text("f", "h", rows[:0]) == "" and rn.rows_text_batch("f", heads, rows[:0]) == ""
+    bad = rows[:2].copy()
+    bad["contig"] = 7
+    with pytest.raises(RuntimeError, match="names record 7 of 3"):
+        rn.rows_text_batch("f", heads, bad)
+
+
 def test_packaging_console_scripts():
     """pyproject.toml declares the reference's three commands (/root/reference pyproject.toml:34-37) on this package's callables."""
     import importlib
