@@ -21,6 +21,7 @@ Prints ONE JSON line (rank 0):
   accuracy              the timed kernel against the plain-fp32 kernels on windows spread over the chromosome
   fast_mode             for information: the fp16-operand kernel (`--fast`) on the same input, and its accuracy
   cpu_baseline          the CPU restatement of the same path (oracle/, all host threads) on a bounded sample
+(stages, e2e, accuracy, fast_mode and cpu_baseline at N = 1 only.)
 """
 import argparse
 import json
@@ -140,7 +141,10 @@ def main():
     def step(p=pipe):
         check(L.dgrp_encode(d_seq.data_ptr(), n, d_idx.data_ptr(), stream_ptr()), "dgrp_encode")
         rows = p.run_idx(d_idx, startpos, contig=rank)     # dgrp_predict_record: the package's default path
+        local_rows[0] = len(rows)
         return gather_records(rows, dev)
+
+    local_rows = [0]                                       # rows of THIS rank's record (the gather returns every rank's on rank 0)
 
     def fence():
         if world > 1:
@@ -172,7 +176,9 @@ def main():
     win_per_launch = kern_windows / max(kern_launches, 1)
     achieved = win_per_launch * FLOP_PER_WINDOW / (avg_ms * 1e-3) / 1e12
 
-    extras = rank == 0 and not args.no_extras
+    # the informational legs run on a lone rank only: they are not part of the contract's line, the other ranks would sit in the final
+    # barrier meanwhile, and a leg that reached a collective (the record gather inside step()) on rank 0 alone would never return
+    extras = rank == 0 and world == 1 and not args.no_extras
     stages = e2e = other = None
     if extras:
         # ---- per-stage milliseconds of one step: the staged form of the same path, a stage at a time
@@ -192,7 +198,7 @@ def main():
             return out, len(rows)
         staged()
         reps = [staged() for _ in range(2)]
-        assert all(r[1] == nrows for r in reps), "staged path and dgrp_predict_record disagree on the row count"
+        assert all(r[1] == local_rows[0] for r in reps), "staged path and dgrp_predict_record disagree on the row count"
         stages = {k: round(float(np.mean([r[0][k] for r in reps])) * 1e3, 3) for k in reps[0][0]}
 
         # ---- end to end: FASTA bytes in host memory -> TSV bytes in host memory, as the command line runs a file
@@ -300,15 +306,15 @@ def main():
                     "q99_window_max_abs_dp": round(acc["q99_window_max"], 8), "max_abs_dp": round(acc["max_abs_diff"], 8),
                     "frac_positions_above_1e-3": round(acc["positions_above_1e-3"] / acc["positions_checked"], 7),
                     "argmax_flips": acc["argmax_flips"], "positions": acc["positions_checked"]}
-        if args.accuracy_windows > 0 and not args.no_extras:
+        if args.accuracy_windows > 0 and extras:
             out["accuracy"] = dict(yardstick="plain-fp32 HIP kernels (dgrp_forward_windows_reference), themselves within 2e-5 of the float64 CPU statement",
                                    kernel=kernel_name, **acc_obj(model.check_accuracy(d_idx, STEP, args.accuracy_windows, level=1 if pipe.split else 0)))
         if other is not None:
             other["kernel"] = fused_name if pipe.split else split_name
-            if args.accuracy_windows > 0:
+            if args.accuracy_windows > 0 and extras:
                 other["accuracy"] = acc_obj(model.check_accuracy(d_idx, STEP, args.accuracy_windows, level=0 if pipe.split else 1))
             out["fast_mode" if pipe.split else "default_mode"] = other
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample_bp)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -131,3 +131,28 @@ def test_contig_sharding_two_ranks_many_records(tmp_path):
     assert open(sharded).read() == open(single).read()
     assert open(single).read().count("\n") > 300
 
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_line_one_and_two_ranks(ranks):
+    """bench.py as the driver launches it -- alone for N = 1, under torch.distributed.run for N > 1 (here 2 ranks on GPU 0 with
+    gloo as the transport) -- with its default legs on: ONE JSON line from rank 0, every rank leaves, within minutes.  (r02: the
+    informational legs once ran a collective on rank 0 alone and an N = 2 launch never returned.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--mbp", "2", "--steps", "2", "--warmup", "1", "--cpu-sample-bp", "20000", "--accuracy-windows", "64"]
+    if ranks == 1:
+        cmd = [sys.executable, "bench.py", "--gpus", "1"] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+               "--master-port", str(29900 + os.getpid() % 90), "bench.py", "--gpus", str(ranks), "--backend", "gloo"] + args
+    res = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=420)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == ranks and out["steps"] == 2 and out["value"] > 0 and out["unit"] == "Mbp/s"
+    assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
+    assert ("cpu_baseline" in out) == (ranks == 1) and ("e2e" in out) == (ranks == 1)
