@@ -476,6 +476,87 @@ def test_fasta_device_ingest_groups(orc, tmp_path, group_records):
             np.testing.assert_array_equal(d1[: one[1]].cpu().numpy(), d_idx[a:a + one[1]].cpu().numpy())
 
 
+def _chunk_table(L, dev, data: bytes, cap: int):
+    import ctypes as C
+    import torch
+    from deepgrp_amd._lib import check
+    from deepgrp_amd.pipeline import stream_ptr
+    d = torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(dev) if data else torch.empty(16, dtype=torch.uint8, device=dev)
+    st, lf, n = np.full(cap, -7, np.int64), np.full(cap, -7, np.int64), C.c_int64(-1)
+    wb = L.dgrp_fasta_chunks_workspace_bytes(cap)
+    work = torch.empty(max(wb, 1), dtype=torch.uint8, device=dev)
+    check(L.dgrp_fasta_chunks(d.data_ptr(), len(data), cap, st.ctypes.data, lf.ctypes.data, C.byref(n), work.data_ptr(), wb, stream_ptr()),
+          "dgrp_fasta_chunks")
+    return n.value, st, lf
+
+
+def test_fasta_chunks_table():
+    """dgrp_fasta_chunks against the definition (a chunk starts at byte 0 and at every '>' directly behind a line feed; first line
+    feed of each chunk, or the size): sizes around the 16-byte vector edge, '>' inside lines, CR LF, no line feed at all, a file of
+    header lines only, the capacity protocol (count only when it does not fit) and the alignment check."""
+    from deepgrp_amd._lib import lib
+    from deepgrp_amd.pipeline import require_gpu
+    dev, L = require_gpu(), lib()
+    rng = np.random.default_rng(12)
+
+    def want(data: bytes):
+        starts = [0] + [i + 1 for i in range(len(data) - 1) if data[i] == 10 and data[i + 1] == 62]
+        lfs = []
+        for k, a in enumerate(starts):
+            b = starts[k + 1] if k + 1 < len(starts) else len(data)
+            j = data.find(b"\n", a, b)
+            lfs.append(j if j >= 0 else len(data))
+        return starts, lfs
+
+    cases = [b">a\nACGT\n", b"ACGT", b">", b"\n", b"\n>", b">\n>\n>\n>", b">x>y\nAC>GT\n>z\r\nAC\r\n", b"\n" * 40 + b">q", b">h\n" + b"A" * 15 + b"\n>i\nC"]
+    for size in (15, 16, 17, 31, 32, 33, 4099):
+        soup = rng.choice(np.frombuffer(b"ACGT\n>\n>", np.uint8), size=size).tobytes()
+        cases.append(soup)
+    cases.append((b">r\nAC\n" * 9000))                                    # 9 000 chunks: more than any first guess
+    for data in cases:
+        starts, lfs = want(data)
+        n, st, lf = _chunk_table(L, dev, data, max(len(starts), 1))
+        assert n == len(starts), data[:40]
+        assert st[:n].tolist() == starts and lf[:n].tolist() == lfs, data[:40]
+        if len(starts) > 1:                                                  # too small a capacity: the count, nothing written
+            n2, st2, _lf2 = _chunk_table(L, dev, data, len(starts) - 1)
+            assert n2 == len(starts) and (st2 == -7).all()
+    assert _chunk_table(L, dev, b"", 4)[0] == 0
+    import ctypes as C
+    import torch
+    d = torch.zeros(64, dtype=torch.uint8, device=dev)
+    work = torch.empty(L.dgrp_fasta_chunks_workspace_bytes(4), dtype=torch.uint8, device=dev)
+    a = np.zeros(4, np.int64)
+    n = C.c_int64()
+    assert L.dgrp_fasta_chunks(d.data_ptr() + 1, 20, 4, a.ctypes.data, a.ctypes.data, C.byref(n), work.data_ptr(), work.numel(), None) != 0
+    assert b"16-byte aligned" in L.dgrp_last_error()
+
+
+def test_fasta_ingest_resident_equals_numpy_table(orc, tmp_path, monkeypatch):
+    """Files up to DGRP_FASTA_RESIDENT_BYTES go up whole and get their chunk table from the device; larger ones are uploaded group by
+    group with a table built in numpy.  Same records either way (many records, odd ones among them, no trailing line feed)."""
+    from deepgrp_amd import fasta
+    rng = np.random.default_rng(21)
+    seq = lambda n: "".join(rng.choice(list("ACGTNacgtn"), size=n))
+    wrap = lambda t, w=70: "\n".join(t[i:i + w] for i in range(0, len(t), w))
+    text = "".join(f">c{k} len\n" + wrap(seq(int(rng.integers(1, 900)))) + "\n" for k in range(300))
+    text += ">odd one\nAC GT\nAC\n>crlf\r\nACGT\r\nAC\r\n>tail\nACGTN"
+    path = tmp_path / "r.fa"
+    path.write_bytes(text.encode())
+
+    def read():
+        out = []
+        for h, rec in fasta.read_multi_fasta_device(str(path), group_records=64):
+            out.append((h, rec.startpos, rec.length, rec.d_idx.cpu().numpy().tobytes()) if isinstance(rec, fasta.DeviceRecord) else (h, rec))
+        return out
+    resident = read()
+    monkeypatch.setattr(fasta, "RESIDENT_BYTES", 0)
+    grouped = read()
+    assert resident == grouped and len(resident) == 303
+    with open(path) as fh:
+        assert [h for h, *_ in resident] == [h for h, _s in orc.read_multi_fasta(fh)]
+
+
 @pytest.mark.parametrize("kind", ("gru", "attention", "lstm", "softmax"))
 def test_predict_record_equals_staged_path(orc, kind):
     """dgrp_predict_record (one call per record) against the staged calls it bundles, incl. a record shorter than a
