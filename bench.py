@@ -20,7 +20,8 @@ Prints ONE JSON line (rank 0):
                         device ingest (A1) + upload over PCIe + the step + TSV text (A12), as the command line runs it
   accuracy              the timed kernel against the plain-fp32 kernels on windows spread over the chromosome
   fast_mode             for information: the fp16-operand kernel (`--fast`) on the same input, and its accuracy
-  cpu_baseline          the CPU restatement of the same path (oracle/, all host threads) on a bounded sample
+  cpu_baseline          the CPU restatement of the same path (oracle/) on bounded samples: all host threads, and one thread
+                        (the reference's default --threads 1)
 (stages, e2e, accuracy, fast_mode and cpu_baseline at N = 1 only.)
 """
 import argparse
@@ -72,21 +73,28 @@ def cpu_baseline(weights, sample_bp: int):
     import numpy as np
     from deepgrp_amd import synthetic
     from oracle import oracle as orc
-    seq = synthetic.synthetic_chromosome(sample_bp, contig=0, flank=1000).decode()
     w = orc.Weights(weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
                     weights["ff_bias"], weights["scale"], T)
     threads = orc.lib().orc_max_threads()
-    sample_bp = min(sample_bp, max(50_000, 25_000 * threads))     # ~10-30 s of wall clock whatever the core count
+    sample_bp = min(sample_bp, max(50_000, 25_000 * threads))     # a few seconds of wall clock whatever the core count
 
-    def factory(idx):
-        return lambda w0, nw: orc.nn_forward(idx, w, STEP, w0, nw, np.float32, threads)
+    def run(bp, nthreads):
+        seq = synthetic.synthetic_chromosome(bp, contig=0, flank=1000).decode()
 
-    t0 = time.perf_counter()
-    rows = orc.predict_contig(seq, factory, T, CLASSES, STEP, BATCH, MIN_MSS, XDROP, True)
-    dt = time.perf_counter() - t0
+        def factory(idx):
+            return lambda w0, nw: orc.nn_forward(idx, w, STEP, w0, nw, np.float32, nthreads)
+        t0 = time.perf_counter()
+        rows = orc.predict_contig(seq, factory, T, CLASSES, STEP, BATCH, MIN_MSS, XDROP, True)
+        return time.perf_counter() - t0, len(rows)
+
+    dt, nrows = run(sample_bp, threads)
+    # the reference's default is --threads 1 (deepgrp/__main__.py:133-139): the same path on one thread, a sample of a few seconds
+    one_bp = 60_000
+    dt1, _ = run(one_bp, 1)
     return {"value": round(sample_bp / dt / 1e6, 5), "unit": "Mbp/s", "cores": int(threads), "kind": "port",
             "sample": f"{sample_bp} bp synthetic contig, full path (oracle/dgrp_oracle.c, float32, OpenMP over windows), "
-                      f"{dt:.1f} s, {len(rows)} rows"}
+                      f"{dt:.1f} s, {nrows} rows",
+            "one_thread": {"value": round(one_bp / dt1 / 1e6, 6), "unit": "Mbp/s", "sample": f"{one_bp} bp, {dt1:.1f} s"}}
 
 
 def main():
