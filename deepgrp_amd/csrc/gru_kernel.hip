@@ -827,7 +827,7 @@ __device__ __forceinline__ float att_elem(const att_chunk (&row)[N], int k)
 }
 
 template <int UP, int CM, typename AT>
-__global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params p)
+__global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? 1 : 2) attention_wave_kernel(const att_params p)
 {
     constexpr int CT = UP <= 64 ? 64 : 128;                  // context registers per lane (butterfly width)
     constexpr int EPC = 16 / sizeof(AT);                     // elements per 16-byte chunk
@@ -876,7 +876,7 @@ __global__ void __launch_bounds__(256, 2) attention_wave_kernel(const att_params
             nxt[j] = t0 + r < T ? *reinterpret_cast<const att_chunk *>(avg + (int64_t)t0 * UP + (int64_t)c * EPC) : att_chunk{ 0u, 0u, 0u, 0u };
         }
     };
-    constexpr bool AHEAD = UP * sizeof(AT) <= 128;           // beyond 64 fp16 / 32 fp32 units the registers for a tile in flight are gone
+    constexpr bool AHEAD = UP * sizeof(AT) <= 128 || UP <= 64;   // beyond 64 units the registers for a tile in flight are gone
     if (AHEAD) fetch(0);
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
