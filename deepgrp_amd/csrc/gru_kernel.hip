@@ -690,6 +690,7 @@ __device__ __forceinline__ int64_t att_window_row(const att_params &p, int64_t w
 // tiles of 64 time steps are staged in LDS; scores e[t] = sum_k scale[k] tanh(q[k] + avg[t,k]) are
 // computed with lane <-> t (each wave a quarter of the units), the softmax over t is kept online
 // (running max / sum, context rescaled per tile), the context update runs with thread <-> unit.
+typedef unsigned att_chunk __attribute__((ext_vector_type(4)));      // 16 bytes as a register vector (HIP's uint4 is a struct)
 #define ATT_TT 64
 #define ATT_WPB 16                                       // windows per workgroup of the wave kernel below
 template <typename AT>
@@ -717,17 +718,34 @@ __global__ void __launch_bounds__(256) attention_kernel(const att_params p)
     }
     float run_m = -INFINITY, run_l = 0.0f;                    // online softmax state (same value in every thread)
     const int kq = UP / 4;                                    // units per wave in the score phase
+    // a tile = [nt][UP] elements in 16-byte chunks, coalesced, held in registers one tile ahead (up to 16 chunks per thread: 256 fp32
+    // units): the next tile's HBM round trip runs under this tile's scores and context
+    constexpr int EPC = 16 / sizeof(AT);                      // elements per chunk
+    constexpr int MAXC = ATT_TT * (256 / EPC) / 256;
+    const int chunks_per_row = UP / EPC;
+    att_chunk pre[MAXC];
+#define ATT_FETCH(t0_)                                                                                              \
+    {                                                                                                               \
+        const int cnt_ = min(ATT_TT, T - (t0_)) * chunks_per_row;                                                   \
+        _Pragma("unroll") for (int j = 0; j < MAXC; ++j) {                                                          \
+            const int i = tid + 256 * j;                                                                            \
+            pre[j] = i < cnt_ ? *reinterpret_cast<const att_chunk *>(avg + (int64_t)(t0_) * UP + (int64_t)i * EPC)  \
+                              : att_chunk{ 0u, 0u, 0u, 0u };                                                        \
+        }                                                                                                           \
+    }
+    ATT_FETCH(0)
     for (int t0 = 0; t0 < T; t0 += ATT_TT) {
         const int nt = min(ATT_TT, T - t0);
         __syncthreads();                                      // previous tile fully consumed (and q/sc/ctx initialised)
-        // stage [nt][UP] elements: 16-byte chunks, coalesced
-        constexpr int EPC = 16 / sizeof(AT);                  // elements per chunk
-        const int chunks_per_row = UP / EPC;
-        for (int i = tid; i < nt * chunks_per_row; i += 256) {
-            const int r = i / chunks_per_row, c8 = i - r * chunks_per_row;
-            *reinterpret_cast<uint4 *>(tile + r * TS + c8 * EPC) =
-                *reinterpret_cast<const uint4 *>(avg + (int64_t)(t0 + r) * UP + c8 * EPC);
+#pragma unroll
+        for (int j = 0; j < MAXC; ++j) {
+            const int i = tid + 256 * j;
+            if (i < nt * chunks_per_row) {
+                const int r = i / chunks_per_row, c8 = i - r * chunks_per_row;
+                *reinterpret_cast<att_chunk *>(tile + r * TS + c8 * EPC) = pre[j];
+            }
         }
+        if (t0 + ATT_TT < T) ATT_FETCH(t0 + ATT_TT)
         __syncthreads();
         // scores: lane <-> t, wave <-> quarter of the units
         float e = 0.0f;
@@ -818,7 +836,6 @@ __device__ __forceinline__ float wave_allsum(float x)
 }
 
 // element k of a row held as 16-byte chunks (fp16: 8 per chunk, fp32: 4)
-typedef unsigned att_chunk __attribute__((ext_vector_type(4)));      // 16 bytes as a register vector (HIP's uint4 is a struct)
 template <typename AT, int N>
 __device__ __forceinline__ float att_elem(const att_chunk (&row)[N], int k)
 {
