@@ -8,8 +8,9 @@
 // same three-pass split: U = U_hi + U_lo, h_{t-1} = h_hi + h_lo as fp16 pairs, U.h ~ U_hi.h_hi + U_hi.h_lo + U_lo.h_hi with fp32
 // accumulation.  Nothing but the input projection and the Dense fragments is resident: the recurrent fragments of both halves
 // (256 units: 96 KB per wave and step) STREAM from L2 through a register ring in consumption order (k-step major, hi then lo,
-// gates in pack order), so the kernel is bound by the L2 -> CU stream, about half the speed of the fp16-operand kernel of the
-// same model.  Correctness first: no staging of vector work into MFMA gaps.
+// gates in pack order).  At 256 units the matrix pipe is the bound (288 MFMAs per wave-step, two waves per SIMD: ~80 % busy), not the
+// stream: keeping fragments resident or a deeper ring changes nothing -- about 0.4 x the speed of the fp16-operand
+// kernel of the same model, which issues a third of the MFMAs.  Correctness first: no staging of vector work into MFMA gaps.
 // GRU: two-reciprocal gate chain of gru_shared.h (beyond 128 units the one-reciprocal form is not offered);
 // LSTM: c = f c + i tanh(z_c), h = o tanh(c) exactly as lstm_fused_kernel evaluates them (accumulators in the exp2 domain).
 #include "gru_shared.h"
