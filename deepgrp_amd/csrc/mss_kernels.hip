@@ -621,14 +621,15 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
 // smaller L, and a merge only hands that L on -- so "none" means  t.L <= Lf,  Lf = L of the run that caused the previous
 // flush (+inf on an empty stack).  Such a run is a cut: the stack work on either side of it is independent, and what the
 // scan needs on the right side is known without the stack: L (the running fold), max, Lf.
-// This kernel is the reference loop WITHOUT the stack: one wave per stretch walks it in 64-element chunks tracking
-// (L, max, Lf, the open run) -- for certified chunks (exact prefix sums, see (3) above) with wave scans over the closed runs
-// of the chunk, no per-run serial work; otherwise element by element -- and reports the cuts (at most one per aligned
-// 64-block), each with its entry L and the number of runs in front of it.  Input that never resets by x-drop (noise-like
-// scores: one stretch of millions of runs, ~270 ns of serial stack work per run) thus splits into thousands of
-// independent pieces; the light walk itself costs a few scans per 64 elements.
-// Passes: like mss_scan_kernel the walk starts from the previous pass's exit L of the stretch in front (fixed point over
-// stretches).  Every walk files its cuts by 64-block; mss_pieces_kernel lines up those of the converged walk.
+// This kernel is the reference loop WITHOUT the stack: one wave per light unit walks it in 64-element chunks tracking
+// (L, max, Lf, the open run) with wave scans over the closed runs of the chunk, no per-run serial work -- the running values
+// from exact prefix sums where the chunk is certified (see (3) above), else from the fold itself, lane after lane (mss_fold);
+// only chunks with subnormal / non-finite values go element by element -- and files the cuts (at most one per aligned
+// 64-block), each with its entry L and the slot of its run.  Input that never resets by x-drop (noise-like scores: one
+// stretch of millions of runs, ~270 ns of serial stack work per run) thus splits into thousands of independent pieces.
+// Passes: a unit starts from the END STATE (mss_light_state) the unit in front of it reached in the previous pass; when no
+// end state changes, every unit started from its predecessor's true state (induction from unit 0).  Every walk files its
+// cuts by 64-block; mss_pieces_kernel lines up those of the converged walk.
 // ------------------------------------------------------------------------------------------
 #define MSS_LIGHT_SUB 2048         // blocks per light unit (131 072 scores: a pass costs a few ms whatever the record's length)
 // what a walk hands to the unit behind it
