@@ -126,7 +126,7 @@ class DeviceRecord:
 
 
 RESIDENT_BYTES = int(os.environ.get("DGRP_FASTA_RESIDENT_BYTES", str(32 << 30)))   # files up to here are uploaded whole (HBM: 288 GB)
-_SLAB = 32 << 20
+_SLAB = 8 << 20                       # pinning host memory costs ~2.4 ms per MB once per process: two small slabs, many turns
 _UPLOAD: dict = {}
 _UPLOAD_LOCK = threading.Lock()       # one file at a time through the two slabs
 
@@ -134,9 +134,12 @@ _UPLOAD_LOCK = threading.Lock()       # one file at a time through the two slabs
 def _upload_file(path, size: int, dev):
     """The file's bytes in HBM: read(2) straight into two pinned slabs in turn, each sent by the copy engine while the next is read."""
     import torch
+    if size <= _SLAB:                     # a small file: one pageable copy is cheaper than pinning anything
+        import numpy as np
+        return torch.from_numpy(np.fromfile(path, dtype=np.uint8, count=size)).to(dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     if key not in _UPLOAD:
-        _UPLOAD[key] = ([torch.empty(_SLAB, dtype=torch.uint8).pin_memory() for _ in range(2)], torch.cuda.Stream(device=dev))
+        _UPLOAD[key] = ([torch.empty(_SLAB, dtype=torch.uint8, pin_memory=True) for _ in range(2)], torch.cuda.Stream(device=dev))
     slabs, copy = _UPLOAD[key]
     with _UPLOAD_LOCK:
         return _upload_through(path, size, dev, slabs, copy)
