@@ -95,6 +95,26 @@ def test_fused_kernel_vs_yardstick_at_bench_shape(dev):
         dm.close()
 
 
+@pytest.mark.parametrize("name,u,T,s,nw", [("cfg5", 256, 500, 25, 512), ("defaults.toml", 60, 342, 50, 1024)])
+def test_fused_kernels_vs_yardstick_at_the_other_baseline_shapes(dev, name, u, T, s, nw):
+    """BASELINE configs[4] (256 units, window 500, stride 25, attention: the streamed split kernel + the tile attention kernel) and
+    configs[0] (the reference's defaults.toml: 60 units, window 342, attention: gru_split_kernel + the wave attention kernel) on
+    hundreds of windows of a synthetic chromosome -- far beyond what the CPU checker covers in the parity tests -- against the
+    plain-fp32 kernels on the device: the default (split operands, fp32 avg[t] spill) to 2e-5 with no more than a near-tie flip,
+    the fp16-operand `--fast` mode inside 1e-3."""
+    from deepgrp_amd import synthetic
+    from deepgrp_amd.pipeline import DeviceModel, upload_sequence
+    _st, d_idx = upload_sequence(synthetic.synthetic_chromosome(T + s * nw + 1000, contig=3, flank=500))
+    w = synthetic.synthetic_weights(u, 5, attention=True, seed=11, gain=1.5)
+    dm = DeviceModel(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], w["scale"], vecsize=T)
+    assert dm.supports_split and dm.attention
+    rs = dm.check_accuracy(d_idx, s, nw, level=1)
+    assert rs["windows_checked"] == nw and rs["max_abs_diff"] < 2e-5 and rs["argmax_flips"] <= 2, (name, rs)
+    r = dm.check_accuracy(d_idx, s, nw, level=0)
+    assert r["max_abs_diff"] < 1e-3 and r["within_1e-3"], (name, r)
+    dm.close()
+
+
 def test_reference_entry_point_errors(dev, orc):
     from deepgrp_amd._lib import lib
     from deepgrp_amd.pipeline import DeviceModel
