@@ -162,8 +162,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     struct frag_ring { half8 h[2][2], l[2][2]; };                 // [k-step parity][row half]
     struct dense_ops { half8 a0, a1, l0, l1; };
     struct fin_state { float d[NW], lg, m, e, s; };
-    auto phase = [&](auto do_x, auto do_y, tile_state &X, tile_state &Y, int tx, int ty) __attribute__((always_inline)) {
-        constexpr bool DO_X = decltype(do_x)::value, DO_Y = decltype(do_y)::value;
+    auto phase = [&](auto do_x, auto do_y, auto do_f, tile_state &X, tile_state &Y, int tx, int ty) __attribute__((always_inline)) {
+        constexpr bool DO_X = decltype(do_x)::value, DO_Y = decltype(do_y)::value, DO_F = decltype(do_f)::value;
         frag_ring F;
         dense_ops D;
         fin_state fs;
@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         float pbh[4][4];
         uint2 pbhv[4], pblv[4];
         uint32_t xp_bf = 4, xp_br = 4;
-        const int tf = ty - 1;                                    // step whose logits Y finishes in this phase
+        const int td = ty - 1;                                    // step whose Dense partials Y stores in this phase
+        const int tf = tx - 2;                                    // step whose logits X finishes in this phase (stored one phase ago, a barrier since)
         if constexpr (DO_X) { F.h[0][0] = X.f0h[0]; F.h[0][1] = X.f0h[1]; F.l[0][0] = X.f0l[0]; F.l[0][1] = X.f0l[1]; }
 #define GAP __builtin_amdgcn_sched_barrier(0);
 #ifdef DGRP_STAMP
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #define AXL(sub) \
     if constexpr (DO_Y) Y.ax[sub] = ldsf4((((sub) & 1) ? Y.tabr : Y.tabf) + 3 * 512 + ((sub) >> 1) * 64);
 #define DS(i)                                                                                                    \
-    if constexpr (DO_Y) Y.ctx.dpart[((size_t)(tf & 1) * 4 * NW + wave) * 64 + lane + (i) * NW * 64] = Y.dpl[i];
+    if constexpr (DO_Y) Y.ctx.dpart[((size_t)(td & 1) * 4 * NW + wave) * 64 + lane + (i) * NW * 64] = Y.dpl[i];
 #define G(e, op) \
     if constexpr (DO_Y) split_gate_op<ONERCP, op>(gt[e], Y.ar[(e) / 4][(e) % 4], Y.ag[(e) / 4][(e) % 4], Y.az[(e) / 4][(e) % 4], Y.ax[(e) / 4][(e) % 4], Y.h[e]);
         // publish sub-tile g = 2 * unit half + row half: 4 consecutive units of row 16 rh + (lane & 15)
@@ -259,11 +260,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 #define CI(g, sub) \
     if constexpr (DO_Y) acc_init(Y, g, sub);
-        // softmax + merge of step tf's logits for the wave's register (window = 4*(lane>>4) + wave, class = lane & 15)
+        // softmax + merge of step tf's logits of tile X (its partials were stored while X was the epilogue tile, one phase and one
+        // barrier ago) for the wave's register (window = 4*(lane>>4) + wave, class = lane & 15)
 #define FN(op)                                                                                                   \
-    if constexpr (DO_Y) {                                                                                        \
+    if constexpr (DO_F) {                                                                                        \
         if constexpr ((op) == 0) {                                                                               \
-            const float *dp_ = Y.ctx.dpart + ((size_t)(tf & 1) * 4 + wave) * NW * 64 + lane;                     \
+            const float *dp_ = X.ctx.dpart + ((size_t)(tf & 1) * 4 + wave) * NW * 64 + lane;                     \
             fs.d[0] = dp_[0]; fs.d[1] = dp_[64]; fs.d[2] = dp_[128]; fs.d[3] = dp_[192];                         \
         } else if constexpr ((op) == 1) {                                                                        \
             const float sum_ = ((fs.d[0] + fs.d[1]) + fs.d[2]) + fs.d[3];                                        \
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         else if constexpr ((op) == 9) { if (MODE != 2) fs.s += row_ror<2>(fs.s); }                               \
         else if constexpr ((op) == 10) { if (MODE != 2) fs.s += row_ror<1>(fs.s); }                              \
         else if constexpr ((op) == 11) { if (MODE != 2) fs.e *= __builtin_amdgcn_rcpf(fs.s); }                   \
-        else { if (Y.pr_on && tf >= 0) emit_value<MODE>(Y.p, Y.ctx, Y.p_off, Y.p_row0, tf, cls, MODE == 2 ? fs.lg : fs.e); } \
+        else { if (X.pr_on && tf >= 0) emit_value<MODE>(X.p, X.ctx, X.p_off, X.p_row0, tf, cls, MODE == 2 ? fs.lg : fs.e); } \
     }
 #include "gru_split2_phase.inc"
 #undef GAP
@@ -312,14 +314,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     };
     first_step(S0);
     first_step(S1);
-    phase(yes, no, S0, S1, 0, 0);
+    phase(yes, no, no, S0, S1, 0, 0);
 #ifdef DGRP_STAMP
     stamp_prev = __builtin_amdgcn_s_memtime();
     const uint64_t stamp_t0 = stamp_prev, stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+    // Register copies the allocator places on a control-flow edge (loop entry, back edge, exit) are VALU reads it does not know to
+    // keep away from the asm MFMAs in front of them: the last MFMAs of a phase have to be complete before the edge.
+#define EDGE_PAD do { asm volatile("s_nop 15\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    EDGE_PAD;
     for (int t = 0; t + 1 < T; ++t) {
-        phase(yes, yes, S1, S0, t, t);          // tile 1's step t      ||  tile 0 finishes step t
-        phase(yes, yes, S0, S1, t + 1, t);      // tile 0's step t + 1  ||  tile 1 finishes step t
+        phase(yes, yes, yes, S1, S0, t, t);          // tile 1's step t      ||  tile 0 finishes step t
+        phase(yes, yes, yes, S0, S1, t + 1, t);      // tile 0's step t + 1  ||  tile 1 finishes step t
+        EDGE_PAD;
     }
 #ifdef DGRP_STAMP
     if (pin.stamps && lane == 0) {
@@ -329,11 +336,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         o[4] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
     }
 #endif
-    phase(yes, yes, S1, S0, T - 1, T - 1);
-    phase(no, yes, S0, S1, T, T - 1);
+    phase(yes, yes, yes, S1, S0, T - 1, T - 1);
+    phase(no, yes, yes, S0, S1, T, T - 1);      // (tile 0's logits of step T - 2 are finished here; tile 1's in its drain)
 
     // drain: Dense and softmax/merge of the last step, image flush
-    auto drain = [&](tile_state &Z) {
+    auto drain = [&](tile_state &Z, bool prev_open) {
         const half8 a0 = lds16(Z.hcur + dense_lane), a1 = lds16(Z.hcur + dense_lane + 16 * HS * 2);
         const half8 l0 = lds16(Z.lcur + dense_lane), l1 = lds16(Z.lcur + dense_lane + 16 * HS * 2);
         if (MODE == 2 && (lane & 15) < Z.ctx.nvalid) split_avg_store(Z.p, Z.ctx.wg_w, T - 1, UP, wave, a0, a1, l0, l1);
@@ -344,11 +351,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) dw[reg * NW * 64] = d[reg];
         __syncthreads();
+        if (prev_open && T > 1) finish_register<NW, MODE>(Z.p, Z.ctx, T - 2, wave, fbias, Z.p_off, Z.p_row0);
         finish_register<NW, MODE>(Z.p, Z.ctx, T - 1, wave, fbias, Z.p_off, Z.p_row0);
         if (MODE == 0 && pin.ospan > 0) flush_image<NW>(Z.p, Z.ctx);
     };
-    drain(S0);
-    drain(S1);
+    drain(S0, false);
+    drain(S1, true);                            // tile 1 stored its partials of step T - 2 in the last phase: no phase of its own follows
 }
 
 template <int MODE, bool ONERCP>

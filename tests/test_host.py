@@ -677,3 +677,29 @@ def test_raise_together_gloo_world2():
         assert p.exitcode == 0
     assert got[1] == "ValueError: negative dimensions are not allowed"
     assert got[0].startswith("RuntimeError: rank 1 failed: ValueError")
+
+
+def test_split2_isa_lint(tmp_path):
+    """tools/lint_split2_isa.py (run by the Makefile on the compiler's output for gru_split2.hip, whose MFMAs are inline asm): a
+    VALU write directly in front of an MFMA operand and an early reader of an MFMA result are hits, an accumulate chain, an LDS
+    load into an operand and a reader 12 wait states later are not."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "lint_split2_isa.py")
+
+    def run(body):
+        p = tmp_path / "k.s"
+        p.write_text("_ZN1x17gru_split2_kernelILi0ELb1EEEv:\n" + "".join(f"\t{ln}\n" for ln in body) + "\ts_endpgm\n")
+        r = subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
+        return r.returncode, r.stdout
+
+    mf = "v_mfma_f32_16x16x32_f16 v[88:91], a[24:27], v[108:111], v[88:91]"
+    rc, out = run(["ds_read_b128 v[108:111], v3", "s_waitcnt lgkmcnt(0)", mf, mf, "v_add_f32_e32 v1, v2, v3"] + ["s_nop 11", "v_exp_f32_e32 v5, v88"])
+    assert rc == 0 and "0 hazard(s)" in out, out
+    rc, out = run(["v_mov_b64_e32 v[90:91], v[38:39]", "v_mov_b64_e32 v[88:89], v[36:37]", mf])          # the copy the allocator once placed
+    assert rc == 1 and out.count("A:") == 2, out
+    rc, out = run(["v_mov_b32_e32 v108, v1", "s_nop 1", mf])                                             # two wait states: enough
+    assert rc == 0, out
+    rc, out = run([mf, "v_add_f32_e32 v1, v2, v3", "v_exp_f32_e32 v5, v89"])                             # result read one state later
+    assert rc == 1 and "B:" in out, out
+    rc, out = run([mf, "v_mfma_f32_16x16x32_f16 v[4:7], a[24:27], v[88:91], v[4:7]"])                    # result as another MFMA's B operand
+    assert rc == 1 and "B:" in out, out

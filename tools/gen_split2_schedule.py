@@ -34,9 +34,10 @@ T, P = 8, 4
 GATE_T = {0, 1, 3, 5, 10}            # transcendental links of the ONERCP chain (the other form has one more: link 8)
 
 
-def gate_pipeline(skew):
+def gate_pipeline(skew, early_ci=False):
     """Gate chains of the 16 elements, element e lagging e*skew links behind element 0 (independent chains interleave);
-    a sub-tile of four elements is published as soon as its last chain is done."""
+    a sub-tile of four elements is published as soon as its last chain is done.  early_ci: the accumulators of a sub-tile
+    restart from their table rows (CI) as soon as its four chains have read them (link 4 is the last reader)."""
     ops, done = [], set()
     tau = 0
     while len(done) < 16:
@@ -44,6 +45,8 @@ def gate_pipeline(skew):
             op = tau - skew * e
             if 0 <= op < 12:
                 ops.append((f"G({e}, {op})", T if op in GATE_T else P))
+                if early_ci and op == 4 and e % 4 == 3:
+                    ops += [(f"CI({g}, {e // 4})", 4) for g in range(3)]
                 if op == 11:
                     done.add(e)
                     if e % 4 == 3:
@@ -56,7 +59,18 @@ def gate_pipeline(skew):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skew", type=int, default=3)
-    ap.add_argument("--bar", type=int, default=112, help="the barrier follows this many of the 144 recurrent MFMAs")
+    ap.add_argument("--late-ci", action="store_true", help="layout 2 with CI behind the barrier (bisecting)")
+    ap.add_argument("--late-fn", action="store_true", help="layout 2 with FN behind the barrier (bisecting)")
+    ap.add_argument("--early-emit", action="store_true",
+                    help="layout 2 with FN's last link (the merge / store, the one link with branches in it) in front of the barrier "
+                         "as well: with nothing but RD0 behind the barrier the register allocator split the accumulators' live ranges "
+                         "and put v_mov copies directly in front of MFMAs (tools/lint_split2_isa.py hazard A, wrong results)")
+    ap.add_argument("--late-ci-sub", type=int, default=-1, help="bisecting: CI of sub-tiles >= this behind the barrier")
+    ap.add_argument("--bar", type=int, default=140, help="the barrier follows this many of the 144 recurrent MFMAs")
+    ap.add_argument("--layout", type=int, default=2,
+                    help="1: softmax/merge (FN) and the accumulators' restart (CI) behind the barrier; 2: FN spread over the whole "
+                         "phase (it finishes the MFMA tile's logits of two steps ago: nothing in this phase feeds it) and CI as soon "
+                         "as a sub-tile's chains have read their accumulators, so that only RD0 waits for the barrier")
     ap.add_argument("--budget", type=float, default=0, help="port cycles per gap in front of the barrier (0 = the queue's average)")
     ap.add_argument("--post-budget", type=float, default=0)
     ap.add_argument("--free-head", type=int, default=4)
@@ -80,11 +94,34 @@ def main():
             if nrec == a.bar:
                 bar_slot = i
     # queue in front of the barrier: Dense partials out, the gate pipeline; behind it: Y's next step, then softmax/merge
-    pre = [(f"DS({i})", 4) for i in range(4)] + gate_pipeline(a.skew)
-    post = [("RD0", 16)] + [(f"CI({g}, {sub})", 4) for g in range(3) for sub in range(4)] + \
-           [("FN(0)", 8), ("-", 0), ("-", 0), ("-", 0), ("FN(1)", 16)] + [(f"FN({i})", 8) for i in range(2, 6)] + [("FN(6)", 16)] + \
-           [(f"FN({i})", 8) for i in range(7, 11)] + [("FN(11)", 12), ("FN(12)", 16)]
+    fn = [("FN(0)", 8), ("FN(1)", 16)] + [(f"FN({i})", 8) for i in range(2, 6)] + [("FN(6)", 16)] + \
+         [(f"FN({i})", 8) for i in range(7, 11)] + [("FN(11)", 12), ("FN(12)", 16)]
+    early_ci = a.layout == 2 and not a.late_ci
+    early_fn = a.layout == 2 and not a.late_fn
+    pre = [(f"DS({i})", 4) for i in range(4)] + gate_pipeline(a.skew, early_ci=early_ci)
+    post = [("RD0", 16)]
+    head = []
+    if not early_ci:
+        post += [(f"CI({g}, {sub})", 4) for g in range(3) for sub in range(4)]
+    if a.late_ci_sub >= 0:
+        late = [x for x in pre if x[0].startswith("CI") and int(x[0][-2]) >= a.late_ci_sub]
+        pre = [x for x in pre if x not in late]
+        post += late
+    if early_fn and not a.early_emit:
+        post += fn[-1:]
+        fn = fn[:-1]
+    if early_fn:
+        # FN(0) (an LDS read) goes into the head gaps, which take nothing that touches the previous phase's accumulators; the
+        # other links at even distances through the queue
+        head = fn[:1]
+        rest = fn[1:]
+        for i, item in enumerate(rest):
+            pre.insert(int((i + 0.5) * len(pre) / len(rest)), item)
+    else:
+        post += fn[:1] + [("-", 0)] * 3 + fn[1:]
     pinned = {0: [("XP(0)", 8), ("RDD", 16)], 1: [("AXL(0)", 4), ("AXL(1)", 4)], 2: [("AXL(2)", 4), ("AXL(3)", 4)], a.xp1: [("XP(1)", 24)]}
+    if head:
+        pinned[3] = list(head)
     for ks in range(3):                                            # fragments of k-step ks+1: early in k-step ks
         si = next(i for i, s in enumerate(slots) if s[1] == ("k", ks, 2))
         pinned.setdefault(si, []).append((f"PF({ks + 1})", 16))
@@ -107,6 +144,8 @@ def main():
         if si >= a.free_head:
             credit += rate
             while queue and (queue[0][1] <= credit + 2 or (si == bar_slot and queue is pre)):
+                if queue[0][0].startswith("CI") and si <= a.xp1:   # the table offsets of the next step are not there yet
+                    break
                 name, c = queue.pop(0)
                 if name == "-":                                    # filler: what follows waits for the next gap
                     credit = min(credit, 0.0)
