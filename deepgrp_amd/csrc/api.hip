@@ -550,16 +550,42 @@ DGRP_EXPORT int dgrp_forward_merge(const dgrp_model *m, const uint8_t *d_idx, in
 // ---- the whole per-record chain of deepgrp/__main__.py:46-83 + :288-292 behind one call ---------------------
 // (A3-A11: windows -> forward -> max-merge -> scores / softmax -> MSS labels -> segments).  Everything lives in the
 // caller's workspace; a host thread per stream can run records concurrently with nothing but this call in between.
+// Bytes of avg[t] spill one launch of an attention model may use.  The spill is the only reason to cut a record's windows into
+// several launches, and a launch that is not a whole number of rounds of workgroups ends with a partly filled one (the one-tile
+// kernels keep 4-8 workgroups of 16 windows on a CU: 16 384-32 768 windows per round; the 4 GiB this cap used to be gave the
+// reference's default model 2.75 rounds per launch -- three rounds of time, 17 % of the pre-pass).  So the cap follows the card:
+// 1/32 of its memory, at most 8 GiB (the command line runs up to 16 records at once, each with a spill of its own);
+// DGRP_SPILL_BYTES overrides it.
+static int64_t spill_cap_bytes()
+{
+    static const int64_t cap = [] {
+        if (const char *e = getenv("DGRP_SPILL_BYTES")) {
+            const long long v = atoll(e);
+            if (v >= (1ll << 20)) return (int64_t)v;
+        }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return (int64_t)(4ll << 30);
+        return std::min<int64_t>(8ll << 30, std::max<int64_t>(1ll << 30, (int64_t)(total_b / 32)));
+    }();
+    return cap;
+}
+
 static int64_t record_window_chunk(const dgrp_model *m)
 {
     if (!m->attention) return 1ll << 20;
-    // keep the avg[t] spill of one launch below ~4 GiB, in whole rounds of workgroups where possible: 4096 windows = 256 CUs x 16
-    // windows (a launch of 4112 windows costs a large model two rounds for the work of one)
+    // whole rounds of workgroups where possible: 32 768 windows = 256 CUs x 8 workgroups x 16 windows is a whole number of rounds
+    // for every recurrent kernel (8, 4, 2 or 1 workgroups of 16 windows, or one of 32, per CU); below that 4096 = 256 CUs x 16
+    // (a launch of 4112 windows costs a large model two rounds for the work of one)
     const int64_t per = (int64_t)m->T * ((int64_t)m->UP * 4 + (int64_t)m->C * 4);
-    int64_t c = (4ll << 30) / per;
-    c = c >= 4096 ? c / 4096 * 4096 : c / 16 * 16;
+    int64_t c = spill_cap_bytes() / per;
+    c = c >= 32768 ? c / 32768 * 32768 : c >= 4096 ? c / 4096 * 4096 : c / 16 * 16;
     if (c < 16) c = 16;
     return c < (1ll << 20) ? c : (1ll << 20);
+}
+
+DGRP_EXPORT int64_t dgrp_forward_window_chunk(const dgrp_model *m)
+{
+    return m ? record_window_chunk(m) : 0;
 }
 
 struct record_layout {

@@ -107,11 +107,7 @@ def _forward_rows(pipe, d_idx: torch.Tensor, w0: int, nw: int, lo: int, hi: int)
         return out
     m.set_precision(1 if getattr(pipe, "split", False) else 0)
     base = out.data_ptr() - lo * C_ * 4
-    chunk = int(getattr(pipe, "chunk_windows", 1 << 20))
-    if m.attention:
-        per = m.vecsize * (((m.units + 31) // 32) * 32 * 4 + m.classes * 4)       # avg[t] as fp32 + the avg half of the logits
-        fit = (4 << 30) // per                            # ~4 GiB of spill per launch, whole rounds of workgroups (4096 windows) if possible
-        chunk = max(16, min(chunk, fit // 4096 * 4096 if fit >= 4096 else fit // 16 * 16))
+    chunk = max(16, min(int(getattr(pipe, "chunk_windows", 1 << 20)), L.dgrp_forward_window_chunk(m.handle)))
     work = None
     w = w0
     while w < w0 + nw:

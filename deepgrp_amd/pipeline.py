@@ -295,11 +295,7 @@ class ContigPipeline:
                     i += 1
                 w0 += nw
             return out
-        chunk = self.chunk_windows
-        if m.attention:
-            per = m.vecsize * (((m.units + 31) // 32) * 32 * 4 + m.classes * 4)       # avg[t] as fp32 + the avg half of the logits
-            fit = (4 << 30) // per                            # ~4 GiB of spill per launch, whole rounds of workgroups (4096 windows) if possible
-            chunk = max(16, min(chunk, fit // 4096 * 4096 if fit >= 4096 else fit // 16 * 16))
+        chunk = max(16, min(self.chunk_windows, L.dgrp_forward_window_chunk(m.handle)))     # attention: the avg[t] spill bounds a launch
         work = None
         w0 = 0
         while w0 < nwin:

@@ -137,6 +137,12 @@ int dgrp_model_set_precision(dgrp_model *m, int level);
 /* ---- A4: model.predict_on_batch (deepgrp/prediction.py:106)
  * Bytes of scratch HBM dgrp_forward_* needs for `nw` windows in one call. */
 int64_t dgrp_forward_workspace_bytes(const dgrp_model *m, int64_t nw);
+/* Windows per call the library itself uses inside dgrp_predict_record, and the size callers of dgrp_forward_merge should cut a
+ * record into (the reference's predict loop, deepgrp/prediction.py:104-110, goes batch by batch; here a "batch" is a launch):
+ * 2^20 without attention; with attention as many as keep the avg[t] spill of one launch within 1/32 of the card's memory, at most
+ * 8 GiB (environment DGRP_SPILL_BYTES overrides), in multiples of 32 768 windows (whole rounds of workgroups for every recurrent
+ * kernel) or, below that, of 4096.  0 for a null model. */
+int64_t dgrp_forward_window_chunk(const dgrp_model *m);
 /* Class probabilities [nw, T, C] float32 of windows w0 .. w0+nw-1 of the index array.  (A workgroup stages its 16
  * windows in LDS: 16 T bytes next to ~25 KiB of state at 128 units, so T up to about 8 000; larger windows are
  * refused with DGRP_EINVAL.) */
