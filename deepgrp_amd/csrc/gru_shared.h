@@ -263,15 +263,29 @@ __device__ __forceinline__ void split_avg_store(const gru_params &p, int64_t wg_
     if (p.avg_f32) {
         // fp32 spill: avg = ((f_hi + f_lo) + (r_hi + r_lo)) / 2 in float, so that the attention kernel sees what the recurrence computed
         // to fp32 rounding (an fp16 spill costs the second kernel 1e-4 in the class probabilities)
+        // Per value: the strand's half sum (hi + lo) / 2 as ONE v_fma_mix_f32 -- fma(hi, 0.5, lo / 2) with both halves widened by the
+        // instruction itself, exact: hi + lo has at most 23 significant bits and lo / 2 is a packed multiply by a power of two (inexact only
+        // for a lo at the bottom of fp16's subnormal range: 3e-8 absolute) -- then one add of
+        // the two strands (the only rounding, the same value as rounding the whole sum and halving it).  32 vector instructions per
+        // step instead of the 64 of converting the four fp16 tiles to float first.
         float *dst = reinterpret_cast<float *>(p.avg) + at;
-        f32x4 v0, v1;
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const _Float16 hf = (_Float16)0.5f;
+        const u32x4_ A0 = __builtin_bit_cast(u32x4_, a0), A1 = __builtin_bit_cast(u32x4_, a1);
+        const u32x4_ L0 = __builtin_bit_cast(u32x4_, l0 * hf), L1 = __builtin_bit_cast(u32x4_, l1 * hf);
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v0[j] = 0.5f * (((float)a0[j] + (float)l0[j]) + ((float)a1[j] + (float)l1[j]));
-            v1[j] = 0.5f * (((float)a0[4 + j] + (float)l0[4 + j]) + ((float)a1[4 + j] + (float)l1[4 + j]));
+        for (int k = 0; k < 4; ++k) {
+            float f0, f1, r0, r1;
+            asm("v_fma_mix_f32 %0, %1, 0.5, %2 op_sel_hi:[1,0,1]" : "=v"(f0) : "v"(A0[k]), "v"(L0[k]));
+            asm("v_fma_mix_f32 %0, %1, 0.5, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(f1) : "v"(A0[k]), "v"(L0[k]));
+            asm("v_fma_mix_f32 %0, %1, 0.5, %2 op_sel_hi:[1,0,1]" : "=v"(r0) : "v"(A1[k]), "v"(L1[k]));
+            asm("v_fma_mix_f32 %0, %1, 0.5, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r1) : "v"(A1[k]), "v"(L1[k]));
+            v[2 * k] = f0 + r0;
+            v[2 * k + 1] = f1 + r1;
         }
-        *reinterpret_cast<f32x4 *>(dst) = v0;
-        *reinterpret_cast<f32x4 *>(dst + 4) = v1;
+        *reinterpret_cast<f32x4 *>(dst) = f32x4{ v[0], v[1], v[2], v[3] };
+        *reinterpret_cast<f32x4 *>(dst + 4) = f32x4{ v[4], v[5], v[6], v[7] };
         return;
     }
     // packed fp16 arithmetic (the halvings are exact; one rounding per add): a quarter of the instructions of a float detour
