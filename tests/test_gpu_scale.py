@@ -147,3 +147,30 @@ def test_250mbp_properties_and_far_offsets(trained):
     for w in range(nfull * B, nwin):
         a = (nfull * r + (w - nfull * B)) * s
         assert bool((merged[a:a + T] >= got[w - w0]).all())
+
+
+def test_900mbp_beyond_32bit_elements(trained):
+    """A record larger than any of BASELINE's configurations: 900 Mbp (the largest chromosomes sequenced so far are of this order),
+    i.e. a merged array of 4.5 G elements -- past 2^32, where an index held in 32 bits anywhere on the path would wrap -- 18 M
+    windows in 18 launches, and (SURVEY 8b iii) still inside the reference's own limit of n < 2^31 for `mss_find_all`.  Checked
+    like the 250 Mbp record: the size-independent properties (incl. the host's own run-length encoding of the labels), the
+    one-call path against the staged one, the LAST windows against the plain-fp32 kernels and the rows they cover bit for bit."""
+    T, s, C, B = 200, 50, 5, 256
+    pipe, st, d_idx, merged, rows = _size_independent_properties(trained, 900_000_000, 5, 1_000_016)
+    n = d_idx.numel()
+    assert n * C > 2 ** 32
+    one_call = pipe.run_idx(d_idx, st)
+    np.testing.assert_array_equal(_rows3(one_call), _rows3(rows))
+    nwin = len(range(0, n - T, s))
+    nw = 2048
+    nfull, r = nwin // B, nwin % B
+    w0 = nfull * B - nw
+    got = trained.forward_windows(d_idx, s, w0, nw)
+    ref = trained.forward_windows_reference(d_idx, s, w0, nw)
+    assert float((got - ref).abs().max()) < 1e-5
+    row_a, row_b = w0 * s + T, nfull * B * s
+    want = torch.zeros((row_b - w0 * s + T, C), dtype=torch.float32, device=merged.device)
+    for w in range(w0, nfull * B):
+        a = (w - w0) * s
+        want[a:a + T] = torch.maximum(want[a:a + T], got[w - w0])
+    assert torch.equal(merged[row_a:row_b], want[T:T + row_b - row_a])
