@@ -642,3 +642,23 @@ def test_cli_console_forms_and_npz_input(tmp_path):
     rows = lambda p: [ln.split("\t")[2:] for ln in open(p).read().splitlines()]
     assert rows(out3) == rows(out2)
     assert {ln.split("\t")[1] for ln in open(out3).read().splitlines()} == {"one.fa.gz"}
+
+
+def test_forward_window_chunk(orc):
+    """dgrp_forward_window_chunk: 2^20 windows without attention; with attention a whole number of rounds of workgroups (multiples
+    of 32 768 windows, or of 4096 when a spill that size does not fit) within the spill cap, and 0 for a null model."""
+    from deepgrp_amd._lib import lib
+    from deepgrp_amd.pipeline import DeviceModel
+    L = lib()
+    assert L.dgrp_forward_window_chunk(None) == 0
+    for u, T, att in ((128, 200, False), (60, 342, True), (128, 200, True), (256, 500, True)):
+        w = orc.Weights.random(u, 5, T, att, seed=3)
+        dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+        c = L.dgrp_forward_window_chunk(dm.handle)
+        if not att:
+            assert c == 1 << 20
+        else:
+            per = T * ((u + 31) // 32 * 32 * 4 + 5 * 4)
+            assert 4096 <= c <= 1 << 20 and c * per <= 8 << 30 and (c + 4096) * per > (8 << 30) // 8
+            assert c % (32768 if c >= 32768 else 4096) == 0
+        dm.close()
