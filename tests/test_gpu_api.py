@@ -662,3 +662,45 @@ def test_forward_window_chunk(orc):
             assert 4096 <= c <= 1 << 20 and c * per <= 8 << 30 and (c + 4096) * per > (8 << 30) // 8
             assert c % (32768 if c >= 32768 else 4096) == 0
         dm.close()
+
+
+def test_attention_chunk_boundaries_do_not_change_results(tmp_path):
+    """The avg[t] spill cuts an attention model's windows into launches (dgrp_forward_window_chunk).  With the cap forced down to
+    1 MiB (DGRP_SPILL_BYTES, read once per process: a child process) a 9 000-base record runs in chunks of 16 windows instead of
+    one launch -- merged probabilities, the one-call record path and the batched path must come out bit for bit the same."""
+    import subprocess
+    import sys
+    script = r'''
+import sys, numpy as np, torch
+from oracle import oracle as orc
+from deepgrp_amd._lib import lib
+from deepgrp_amd.pipeline import ContigPipeline, DeviceModel
+out = sys.argv[1]
+res = {}
+for name, (u, T) in {"d": (60, 342), "b": (128, 200)}.items():
+    w = orc.Weights.random(u, 5, T, True, seed=5, gain=1.5)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    res[name + "_chunk"] = np.int64(lib().dgrp_forward_window_chunk(dm.handle))
+    rng = np.random.default_rng(u)
+    idx = torch.from_numpy(rng.choice(5, size=9000, p=[0.24, 0.25, 0.25, 0.24, 0.02]).astype(np.uint8)).cuda()
+    pipe = ContigPipeline(dm, 50, 256, 50, 50, True)
+    res[name + "_merged"] = pipe.merged(idx).cpu().numpy()
+    rows = pipe.run_idx(idx, 7)
+    res[name + "_rows"] = np.stack([rows["start"], rows["end"], rows["label"]], 1)
+    base = torch.cat([idx, idx[:4000], idx[2000:7000]])
+    rb = pipe.run_batch(base, [0, 9000, 13000], [9000, 4000, 5000], [0, 0, 0], [0, 1, 2])
+    res[name + "_batch"] = np.stack([rb["start"], rb["end"], rb["label"], rb["contig"]], 1)
+    dm.close()
+np.savez(out, **res)
+'''
+    outs = []
+    for tag, env in (("whole", {}), ("cut", {"DGRP_SPILL_BYTES": str(1 << 20)})):
+        o = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, "-c", script, str(o)], env=dict(os.environ, PYTHONPATH=ROOT, **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(o))
+    whole, cut = outs
+    assert int(whole["d_chunk"]) >= 4096 and int(cut["d_chunk"]) == 16 and int(cut["b_chunk"]) == 16
+    for k in whole.files:
+        if not k.endswith("_chunk"):
+            np.testing.assert_array_equal(whole[k], cut[k], err_msg=k)
