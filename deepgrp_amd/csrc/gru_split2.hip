@@ -19,13 +19,16 @@
 //     lane's window (forward and complemented reverse), read as the MFMA chain's C operand.
 //   * TWO row tiles (2 x 16 windows) per workgroup, software-pipelined against each other: a "phase" is the 150 MFMAs of
 //     one tile's step (X) with the whole epilogue of the other tile's step (Y) -- gate chains, fp16 hi/lo publish, the
-//     workgroup barrier, softmax + max-merge of the step before, table rows and first fragments of Y's next step -- cut
+//     workgroup barrier, table rows and first fragments of Y's next step -- and the softmax + max-merge of X's own logits of
+//     two steps ago (stored while X was the epilogue tile, a barrier since: nothing in this phase feeds them), cut
 //     into single operations and dropped into the gaps BETWEEN X's MFMAs (a wave issues in order; an MFMA holds the issue
-//     port for 8 of its 16 cycles).  The barrier itself sits inside X's MFMA stream.
+//     port for 8 of its 16 cycles).  The barrier itself sits inside X's MFMA stream, four MFMAs from its end.
 //   * The order of that interleave is generated (tools/gen_split2_schedule.py -> gru_split2_phase.inc) and pinned with
 //     sched_barrier between gaps; the MFMAs are asm volatile, which the compiler keeps in program order.
 //
-// Inline-asm obligations (cdna_hip_programming.md 5.7) and how they are met:
+// Inline-asm obligations (cdna_hip_programming.md 5.7) and how they are met -- by construction, and CHECKED on the compiler's
+// output at every build (tools/lint_split2_isa.py, run by the Makefile): the register allocator is free to put a v_mov copy of an
+// accumulator directly in front of the MFMA that takes it as C, and did so for one schedule variant (wrong results, no fault):
 //   - an MFMA's result is read by compiler-scheduled code only many MFMAs later (the generator keeps the first gaps of a
 //     phase free of anything that touches the previous phase's accumulators or Dense result);
 //   - no MFMA operand is written by VALU code: fragments, table rows and Dense operands come straight from LDS reads, which

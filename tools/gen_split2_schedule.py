@@ -14,14 +14,15 @@ halves x 2 row halves) + 6 Dense -- with tile Y's epilogue cut into single opera
     XP(op)                     Y: bases of its next step (0: read the two bytes, 1: table row offsets)
     BAR                        s_waitcnt lgkmcnt(0) + s_barrier, flip Y's ping-pong
     RD0 CI(g, sub)             Y's next step: first fragments; accumulator sub of gate g starts as its table row
-    FN(op)                     Y: softmax + max-merge of the previous step's logits (0..12)
+    FN(op)                     X: softmax + max-merge of ITS logits of two steps ago (0..12; stored a phase and a barrier earlier)
     GAP                        sched_barrier(0)
     ST(i)                      diagnostic build only (-DDGRP_STAMP): add the cycles since the last stamp to section i
 
 Cost model (cycles of the SIMD's issue port, MI355X_MICROARCH.md "vector-instruction ISSUE cost"): transcendental 8, plain
 VALU 4, LDS instruction 4.  A 16x16x32 MFMA occupies the pipe for 16 cycles and the port for 8; the epilogue's ~1500 port
 cycles do not fit the 150 x 8 free ones, so the stream is paced by the port and the aim is an even spread: BUDGET cycles of
-work per gap, taken in order from the queue in front of the barrier and the one behind it.  Nothing that reads the previous
+work per gap, taken in order from the queue in front of the barrier and the one behind it (layout 2: only RD0 and FN's last,
+branching link are behind it).  Nothing that reads the previous
 phase's accumulators or Dense result goes into the first FREE_HEAD gaps (MFMA result -> VALU read needs wait states the
 compiler does not pad behind inline asm).
 
