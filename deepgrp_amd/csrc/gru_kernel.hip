@@ -41,7 +41,7 @@
 //   gru_split2_kernel<MODE>           split operands, 97-128 units: one wave per SIMD, two row tiles per wave, U_hi and U_lo
 //                                     resident (512-register budget)
 //   lstm_fused_kernel<NW,MODE>        rnn = "LSTM", fp16 operands
-//   attention_kernel / attention_wave_kernel<UP,CM>   second pass of attention models (after a MODE 2 pre-pass)
+//   attention_wave_kernel<UP,CM> (up to 64 units) / attention_row_kernel<AT,EPL,TT> (65-256 units)   second pass of attention models (after a MODE 2 pre-pass)
 // MODE 0: forward + max-merge into [n, C]; 1: probabilities [nw, T, C]; 2: attention pre-pass (avg[t] spill + partial logits)
 #include "gru_shared.h"
 template <int NW, int MODE, bool ONERCP>
@@ -686,129 +686,10 @@ __device__ __forceinline__ int64_t att_window_row(const att_params &p, int64_t w
     return rc.out_row + dgrp_place_row(rc.place, wl - rc.win_first, p.s);
 }
 
-// One workgroup (256 threads) per window, ONE pass over the window's avg[t] tile (read from HBM once):
-// tiles of 64 time steps are staged in LDS; scores e[t] = sum_k scale[k] tanh(q[k] + avg[t,k]) are
-// computed with lane <-> t (each wave a quarter of the units), the softmax over t is kept online
-// (running max / sum, context rescaled per tile), the context update runs with thread <-> unit.
 typedef unsigned att_chunk __attribute__((ext_vector_type(4)));      // 16 bytes as a register vector (HIP's uint4 is a struct)
-#define ATT_TT 64
 #define ATT_WPB 16                                       // windows per workgroup of the wave kernel below
-template <typename AT>
-__global__ void __launch_bounds__(256) attention_kernel(const att_params p)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int T = p.T, UP = p.UP, C = p.C;
-    const int TS = UP + 8;                                   // padded tile row (halves): conflict-free column walks
-    AT *tile = reinterpret_cast<AT *>(smem);                  // [ATT_TT][TS]
-    float *q = reinterpret_cast<float *>(tile + ATT_TT * TS);   // [UP]
-    float *sc = q + UP;                                       // [UP] scale
-    float *ctx = sc + UP;                                     // [UP]
-    float *epart = ctx + UP;                                  // [4][ATT_TT]
-    float *pw = epart + 4 * ATT_TT;                           // [ATT_TT] softmax numerators of the tile
-    float *red = pw + ATT_TT;                                 // [8]
-    float *cl = red + 8;                                      // [16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t wl = blockIdx.x;
-    const AT *avg = reinterpret_cast<const AT *>(p.avg) + wl * (int64_t)T * UP;
-
-    for (int k = tid; k < UP; k += 256) {
-        q[k] = (float)avg[(int64_t)(T - 1) * UP + k];         // Average of the two final states = avg[T-1]
-        sc[k] = p.scale[k];
-        ctx[k] = 0.0f;
-    }
-    float run_m = -INFINITY, run_l = 0.0f;                    // online softmax state (same value in every thread)
-    const int kq = UP / 4;                                    // units per wave in the score phase
-    // a tile = [nt][UP] elements in 16-byte chunks, coalesced, held in registers one tile ahead (up to 16 chunks per thread: 256 fp32
-    // units): the next tile's HBM round trip runs under this tile's scores and context
-    constexpr int EPC = 16 / sizeof(AT);                      // elements per chunk
-    constexpr int MAXC = ATT_TT * (256 / EPC) / 256;
-    const int chunks_per_row = UP / EPC;
-    att_chunk pre[MAXC];
-#define ATT_FETCH(t0_)                                                                                              \
-    {                                                                                                               \
-        const int cnt_ = min(ATT_TT, T - (t0_)) * chunks_per_row;                                                   \
-        _Pragma("unroll") for (int j = 0; j < MAXC; ++j) {                                                          \
-            const int i = tid + 256 * j;                                                                            \
-            pre[j] = i < cnt_ ? *reinterpret_cast<const att_chunk *>(avg + (int64_t)(t0_) * UP + (int64_t)i * EPC)  \
-                              : att_chunk{ 0u, 0u, 0u, 0u };                                                        \
-        }                                                                                                           \
-    }
-    ATT_FETCH(0)
-    for (int t0 = 0; t0 < T; t0 += ATT_TT) {
-        const int nt = min(ATT_TT, T - t0);
-        __syncthreads();                                      // previous tile fully consumed (and q/sc/ctx initialised)
-#pragma unroll
-        for (int j = 0; j < MAXC; ++j) {
-            const int i = tid + 256 * j;
-            if (i < nt * chunks_per_row) {
-                const int r = i / chunks_per_row, c8 = i - r * chunks_per_row;
-                *reinterpret_cast<att_chunk *>(tile + r * TS + c8 * EPC) = pre[j];
-            }
-        }
-        if (t0 + ATT_TT < T) ATT_FETCH(t0 + ATT_TT)
-        __syncthreads();
-        // scores: lane <-> t, wave <-> quarter of the units
-        float e = 0.0f;
-        if (lane < nt) {
-            const AT *row = tile + lane * TS + wave * kq;
-            const float *qq = q + wave * kq, *ss = sc + wave * kq;
-            for (int k = 0; k < kq; ++k) e += ss[k] * fast_tanh(qq[k] + (float)row[k]);
-        }
-        epart[wave * ATT_TT + lane] = e;
-        __syncthreads();
-        float et = lane < nt ? epart[lane] + epart[ATT_TT + lane] + epart[2 * ATT_TT + lane] + epart[3 * ATT_TT + lane] : -INFINITY;
-        float tm = et;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
-        const float new_m = fmaxf(run_m, tm);
-        const float alpha = __expf(run_m - new_m);            // 0 on the first tile (run_m = -inf)
-        const float pt = lane < nt ? __expf(et - new_m) : 0.0f;
-        float ps = pt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
-        run_l = run_l * alpha + ps;
-        run_m = new_m;
-        if (wave == 0) pw[lane] = pt;
-        __syncthreads();
-        // context: thread <-> unit (two halves of the tile's time steps when UP <= 128)
-        for (int k = tid; k < UP; k += 256) {
-            float acc = 0.0f;
-            for (int t = 0; t < nt; ++t) acc += pw[t] * (float)tile[t * TS + k];
-            ctx[k] = ctx[k] * alpha + acc;
-        }
-    }
-    __syncthreads();
-    const float inv = 1.0f / run_l;
-    if (tid < 16) {
-        float acc = 0.0f;
-        if (tid < C)
-            for (int k = 0; k < UP; ++k) acc += ctx[k] * p.wtop[k * 16 + tid];
-        cl[tid] = acc * inv;
-    }
-    __syncthreads();
-    int64_t limit = p.n;
-    const int64_t row0 = p.merge ? att_window_row(p, wl, &limit) : wl * (int64_t)T;
-    const float *pl = p.pl + wl * (int64_t)T * C;
-    for (int t = tid; t < T; t += 256) {
-        float lg[16];
-        float mx = -INFINITY;
-        for (int c = 0; c < C; ++c) { lg[c] = pl[t * C + c] + cl[c]; mx = fmaxf(mx, lg[c]); }
-        float den = 0.0f;
-        for (int c = 0; c < C; ++c) { lg[c] = __expf(lg[c] - mx); den += lg[c]; }
-        for (int c = 0; c < C; ++c) {
-            const float v = lg[c] / den;
-            if (p.merge) {
-                if (row0 + t < limit) atomicMax(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
-            } else {
-                p.out[(row0 + t) * C + c] = v;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// The same computation with ONE WAVE per window and no workgroup barrier (units <= 128): the tile kernel above
-// spends its time in __syncthreads and in a context phase that keeps a quarter of the threads busy.  Here
+// Models up to 64 units: ONE WAVE per window and no workgroup barrier.  Here
 // lane <-> time step throughout: a lane reads its own avg[t] row (UP halves, contiguous) into registers, scores
 // it against q (packed math, two units per instruction; 2^(c(q+a)) with c folded into the LDS copy of q, and
 // tanh = 1 - 2r folded into the scale: e[t] = sum(scale) - 2 sum_k scale[k] r[k]), keeps the softmax over t
@@ -833,6 +714,133 @@ __device__ __forceinline__ float wave_allsum(float x)
     x = row_allsum(x);
     const float a = lane_value(x, 0), b = lane_value(x, 16), c = lane_value(x, 32), d = lane_value(x, 48);
     return (a + b) + (c + d);
+}
+
+// ------------------------------------------------------------------------------------------
+// Models of 65-256 units: ONE WAVE per window, no LDS, no barrier (the workgroup-per-window kernel this replaces staged 64-step
+// tiles in LDS behind four barriers each and read its fp32 spill at 2.5 TB/s; this one: 4.4 TB/s).  lane <-> EPL consecutive units throughout
+// (2 up to 128 units, 4 beyond), so a step's row is ONE coalesced load per lane and q, the scale and the context are per-lane
+// registers.  A tile = TT steps (8 or 4) held in registers; small tiles keep the kernel at 3-4 waves per SIMD, which cover each
+// other's loads (tiles of 16 steps: 12.4 ms per 400 k windows of 128 units, of 8: 9.3 ms; 32 with the next tile prefetched: spills):
+//   scores    every lane's share  sum_j s2[j] r[j]  of each step (r = 1 / (1 + 2^(c (q + a))), tanh = 1 - 2 r folded into s2 = -2 scale);
+//             the TT per-lane shares meet in a halving butterfly (after the stage of partner lane ^ M a lane keeps the upper half of
+//             its values if its bit M is set, the lower half otherwise, each summed with the partner's): log2(TT) stages of
+//             TT/2, TT/4, .. 1 exchanges leave step  lane >> (6 - log2 TT)  of the tile in every lane, complete after 6 - log2 TT
+//             more pair sums;
+//   softmax   over t kept online across tiles (running max / sum, context rescaled per tile), wave reductions by DPP + readlane;
+//   context   ctx[j] += p[t] a[t, j] with p[t] read from the lane that holds it (v_readlane: a scalar operand of the fma).
+// Then ctx . W_top by lane shares + wave sums, and the output rows as in the tile kernel.
+// ------------------------------------------------------------------------------------------
+template <typename AT, int EPL, int TT>
+__global__ void __launch_bounds__(256, 3) attention_row_kernel(const att_params p)
+{
+    constexpr int LT = TT == 32 ? 5 : TT == 16 ? 4 : TT == 8 ? 3 : 2, SH = 6 - LT;    // a tile's step t ends up in the 2^SH lanes t << SH ..
+    struct alignas(sizeof(AT) * EPL) row_t { AT v[EPL]; };
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wl = (int64_t)blockIdx.x * 4 + wave;
+    if (wl >= p.nw) return;                                   // (no barrier anywhere below)
+    const int T = p.T, UP = p.UP, C = p.C;
+    const int k0 = lane * EPL;
+    const bool on = k0 < UP;                                  // UP / EPL lanes carry units
+    const AT *avg = reinterpret_cast<const AT *>(p.avg) + wl * (int64_t)T * UP + (on ? k0 : 0);
+    const float cexp = 2.8853900817779268f;                   // tanh(x) = 1 - 2 / (1 + 2^(c x))
+    float cq[EPL], s2[EPL], ctx[EPL];
+    float ssum = 0.0f;
+    {
+        const row_t qr = *reinterpret_cast<const row_t *>(avg + (int64_t)(T - 1) * UP);          // Average of the two final states = avg[T-1]
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const float sc = on ? p.scale[k0 + j] : 0.0f;     // idle lanes read lane 0's units and weigh them with 0
+            cq[j] = cexp * (float)qr.v[j];
+            s2[j] = -2.0f * sc;
+            ssum += sc;
+            ctx[j] = 0.0f;
+        }
+    }
+    ssum = wave_allsum(ssum);                                 // e[t] = sum(scale) - 2 sum_k scale[k] r[t, k]
+    float run_m = -INFINITY, run_l = 0.0f;
+    for (int t0 = 0; t0 < T; t0 += TT) {
+        row_t rows[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i)                          // (steps behind the window's end: its last row again, weight 0 below)
+            rows[i] = *reinterpret_cast<const row_t *>(avg + (int64_t)min(t0 + i, T - 1) * UP);
+        float ep[TT];
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf((float)rows[i].v[j], cexp, cq[j])));
+                acc = __builtin_fmaf(s2[j], r, acc);
+            }
+            ep[i] = acc;
+        }
+        // halving butterfly over the lanes: TT values per lane -> one
+#pragma unroll
+        for (int n = TT / 2, M = 32; n >= 1; n >>= 1, M >>= 1) {
+            const bool up = (lane & M) != 0;
+#pragma unroll
+            for (int i = 0; i < n; ++i) {
+                const float send = up ? ep[i] : ep[i + n], keep = up ? ep[i + n] : ep[i];
+                ep[i] = keep + __shfl_xor(send, M);
+            }
+        }
+        float e = ep[0];
+#pragma unroll
+        for (int M = (1 << SH) >> 1; M >= 1; M >>= 1) e += __shfl_xor(e, M);
+        const int tl = lane >> SH;                            // the step of the tile this lane holds
+        const bool valid = t0 + tl < T;
+        e = valid ? ssum + e : -INFINITY;
+        const float new_m = fmaxf(run_m, wave_allmax(e));
+        const float alpha = __builtin_amdgcn_exp2f(1.4426950408889634f * (run_m - new_m));     // 0 on the first tile (run_m = -inf)
+        const float pt = valid ? __builtin_amdgcn_exp2f(1.4426950408889634f * (e - new_m)) : 0.0f;
+        run_l = run_l * alpha + wave_allsum((lane & ((1 << SH) - 1)) == 0 ? pt : 0.0f);       // a step sits in 2^SH lanes: count it once
+        run_m = new_m;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) ctx[j] *= alpha;
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            const float w = lane_value(pt, i << SH);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) ctx[j] = __builtin_fmaf(w, (float)rows[i].v[j], ctx[j]);
+        }
+    }
+    // ctx . W_top (rows of W_top: this lane's units), normalised; the same value in every lane
+    const float inv = 1.0f / run_l;
+    float cl[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float part = 0.0f;
+        if (c < C && on) {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) part = __builtin_fmaf(ctx[j], p.wtop[(k0 + j) * 16 + c], part);
+        }
+        cl[c] = c < C ? wave_allsum(part) * inv : 0.0f;
+    }
+    int64_t limit = p.n;
+    const int64_t row0 = p.merge ? att_window_row(p, wl, &limit) : wl * (int64_t)T;
+    const float *pl = p.pl + wl * (int64_t)T * C;
+    for (int t = lane; t < T; t += 64) {
+        float lg[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) { lg[c] = pl[t * C + c] + cl[c]; mx = fmaxf(mx, lg[c]); }
+        float den = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) { lg[c] = __expf(lg[c] - mx); den += lg[c]; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) {
+                const float v = lg[c] / den;
+                if (p.merge) {
+                    if (row0 + t < limit) atomicMax(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
+                } else {
+                    p.out[(row0 + t) * C + c] = v;
+                }
+            }
+    }
 }
 
 // element k of a row held as 16-byte chunks (fp16: 8 per chunk, fp32: 4)
@@ -1307,12 +1315,11 @@ int dgrp_attention_launch_recs(const dgrp_model *m, int64_t s, dgrp_placement pl
     // element type of the avg[t] spill: fp32 behind a split-operand pre-pass (the level the model is set to), else fp16
     const bool f32 = m->precision == 1;
     const int esz = f32 ? 4 : 2;
-    const size_t lds = (size_t)ATT_TT * (m->UP + 8) * esz + (size_t)(3 * m->UP + 4 * ATT_TT + ATT_TT + 8 + 16) * sizeof(float);
     DGRP_REQUIRE(nw < (1ll << 31), "too many windows in one launch");
     p.ospan = 0;
     const int64_t want = (ATT_WPB - 1) * s + m->T;
     const unsigned grid = (unsigned)((nw + ATT_WPB - 1) / ATT_WPB);
-    if (m->UP <= 64 && !getenv("DGRP_ATT_TILE")) {
+    if (m->UP <= 64) {
         // one wave per window; beyond 64 units its per-lane context (UP registers) no longer fits beside the row
         const int stat = 4 * m->UP * 2 * 4 + 4 * 64 * (m->UP + 16 / esz) * esz;  // qs + tiles (static LDS of the kernel)
         if (merge) {
@@ -1341,14 +1348,15 @@ int dgrp_attention_launch_recs(const dgrp_model *m, int64_t s, dgrp_placement pl
         DGRP_LAUNCH_CHECK();
         return DGRP_OK;
     }
-    static bool tile_configured = false;
-    if (!tile_configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)attention_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DGRP_HIP(hipFuncSetAttribute((const void *)attention_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        tile_configured = true;
+    // 65-256 units: one wave per window straight from HBM (attention_row_kernel), 2 units per lane up to 128 units, 4 beyond
+    const unsigned rgrid = (unsigned)((nw + 3) / 4);
+    if (m->UP <= 128) {
+        if (f32) hipLaunchKernelGGL((attention_row_kernel<float, 2, 8>), dim3(rgrid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attention_row_kernel<_Float16, 2, 4>), dim3(rgrid), dim3(256), 0, stream, p);
+    } else {
+        if (f32) hipLaunchKernelGGL((attention_row_kernel<float, 4, 8>), dim3(rgrid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attention_row_kernel<_Float16, 4, 8>), dim3(rgrid), dim3(256), 0, stream, p);
     }
-    if (f32) hipLaunchKernelGGL(attention_kernel<float>, dim3((unsigned)nw), dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL(attention_kernel<_Float16>, dim3((unsigned)nw), dim3(256), lds, stream, p);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
 }
