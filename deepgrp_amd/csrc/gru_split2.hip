@@ -44,7 +44,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef DGRP_SPLIT_DROP
 #define DGRP_SPLIT_DROP 0
 #endif
-// order of the 12 MFMAs of a pass: 0 = gate, unit half, row half (two in a row share the A fragment); 1 = row half, gate, unit half (six share B)
+// order of the 36 MFMAs of a k-step: 0 = pass, gate, unit half, row half (two in a row share the A fragment); 1 = pass, row half, gate, unit
+// half (six share B); 2 = gate, unit half, pass, row half (four in a row share U_hi, then two U_lo; an accumulator's passes two MFMAs apart)
 #ifndef DGRP_MK_ORDER
 #define DGRP_MK_ORDER 0
 #endif
@@ -186,9 +187,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #endif
         // MFMA n (0..35) of k-step ks: pass n / 12 (hi.h_hi, hi.h_lo, lo.h_hi), then gate, unit half, row half
 #define M_K(ks, n)                                                                                               \
-    if constexpr (DO_X && !(DGRP_SPLIT_DROP == 1 && (n) >= 24) && !(DGRP_SPLIT_DROP == 2 && (n) >= 12 && (n) < 24)) { \
-        constexpr int ps_ = (n) / 12, g_ = DGRP_MK_ORDER == 0 ? ((n) % 12) / 4 : ((n) % 6) / 2, uh_ = DGRP_MK_ORDER == 0 ? ((n) % 4) / 2 : (n) % 2, \
-                      rh_ = DGRP_MK_ORDER == 0 ? (n) % 2 : ((n) % 12) / 6, sub_ = 2 * uh_ + rh_;                                   \
+    if constexpr (DO_X && !(DGRP_MK_ORDER != 2 && DGRP_SPLIT_DROP == 1 && (n) >= 24) && !(DGRP_MK_ORDER != 2 && DGRP_SPLIT_DROP == 2 && (n) >= 12 && (n) < 24)) { \
+        constexpr int ps_ = DGRP_MK_ORDER == 2 ? ((n) % 6) / 2 : (n) / 12,                                                          \
+                      g_ = DGRP_MK_ORDER == 0 ? ((n) % 12) / 4 : DGRP_MK_ORDER == 2 ? (n) / 12 : ((n) % 6) / 2,                    \
+                      uh_ = DGRP_MK_ORDER == 0 ? ((n) % 4) / 2 : DGRP_MK_ORDER == 2 ? ((n) / 6) % 2 : (n) % 2,                     \
+                      rh_ = DGRP_MK_ORDER == 1 ? ((n) % 12) / 6 : (n) % 2, sub_ = 2 * uh_ + rh_;                                   \
         const half8 &b_ = ps_ == 1 ? F.l[(ks) & 1][rh_] : F.h[(ks) & 1][rh_];                                    \
         const u32x4 &w_ = ps_ == 2 ? W.lo[g_][ks][uh_] : W.hi[g_][ks][uh_];                                      \
         if constexpr (g_ == 0) MFMA_R(X.ar[sub_], w_, b_);                                                       \
