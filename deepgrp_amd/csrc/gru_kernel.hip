@@ -402,6 +402,9 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
 #ifndef DGRP_SPLIT_PF
 #define DGRP_SPLIT_PF 6
 #endif
+#ifndef DGRP_SPLIT_PIN
+#define DGRP_SPLIT_PIN 1
+#endif
     constexpr int UP = 32 * NW, KS = UP / 16, HS = UP + 8, NLO = 3 * KS, PF = DGRP_SPLIT_PF < NLO ? DGRP_SPLIT_PF : NLO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -492,6 +495,10 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
                 wl[gi] = __builtin_bit_cast(half8, q[f % PF]);
                 if (f + PF < NLO) q[f % PF] = mylo[(size_t)(f + PF) * 64];
             }
+            // Keep the refills HERE for the attention pre-pass: left alone the scheduler sinks each load to two MFMAs in front of its
+            // use (the ring then hides nothing: 2 500 of a wave-step's 6 700 cycles waiting on vmcnt).  defaults.toml shape +4.7 %;
+            // without the avg[t] stores in the step (MODE 0 / 1) the sunk form is 1 % faster at 64 units and stays.
+            if (DGRP_SPLIT_PIN && MODE == 2) __builtin_amdgcn_sched_barrier(0);
             ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], hf, ar, 0, 0, 0);
             ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], hf, ag, 0, 0, 0);
             az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[k], hf, az, 0, 0, 0);
