@@ -517,3 +517,23 @@ def test_window_size_beyond_lds_is_refused(dev, orc):
     want = orc.nn_forward(idx, w, 16, 0, 2, np.float64)
     assert np.abs(got - want).max() < 1e-3
     dm.close()
+
+
+@pytest.mark.parametrize("u,T,C_,nw", [(72, 5, 2, 9), (96, 37, 16, 21), (130, 37, 5, 18), (192, 13, 16, 7), (250, 70, 3, 6), (128, 1, 5, 5)])
+def test_attention_row_kernel_edges(dev, orc, u, T, C_, nw):
+    """attention_row_kernel (models of 65-256 units) where its lane map has idle lanes (units / 2 or / 4 lanes carry units: 36, 48, 33,
+    48, 63 of 64), windows shorter than one register tile and not a multiple of it, and 2 / 16 classes: window probabilities within
+    1e-3 (fp16 operands, fp16 spill) and 1e-5 (split operands, fp32 spill) of the float64 statement."""
+    rng = np.random.default_rng(u * 131 + T)
+    s = max(1, T // 3)
+    w, dm = _model(orc, u, T, True, 1.5, seed=11, C_=C_)
+    idx = _seq_idx(rng, (nw + 2) * s + T)
+    want = orc.nn_forward(idx, w, s, 1, nw, np.float64)
+    for level, tol in ((0, 1e-3), (1, 1e-5)):
+        dm.set_precision(level)
+        got = dm.forward_windows(_t(idx, dev), s, 1, nw).cpu().numpy()
+        assert got.shape == want.shape
+        err = np.abs(got - want).max()
+        print(f"u={u} T={T} C={C_} level={level}: max |dp| = {err:.2e}")
+        assert err < tol
+    dm.close()
