@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(64 * NW, 2) gru_split_kernel(const gru_params 
             // Keep the refills HERE for the attention pre-pass: left alone the scheduler sinks each load to two MFMAs in front of its
             // use (the ring then hides nothing: 2 500 of a wave-step's 6 700 cycles waiting on vmcnt).  defaults.toml shape +4.7 %;
             // without the avg[t] stores in the step (MODE 0 / 1) the sunk form is 1 % faster at 64 units and stays.
-            if (DGRP_SPLIT_PIN && MODE == 2) __builtin_amdgcn_sched_barrier(0);
+            if (DGRP_SPLIT_PIN && (MODE == 2 || DGRP_SPLIT_PIN == 2)) __builtin_amdgcn_sched_barrier(0);
             ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(Br[k], hf, ar, 0, 0, 0);
             ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bg[k], hf, ag, 0, 0, 0);
             az = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bz[k], hf, az, 0, 0, 0);

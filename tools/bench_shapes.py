@@ -11,7 +11,10 @@ cases = [("defaults.toml  u=60  T=342 s=50 attention", 60, 342, 50, True, 20e6),
          ("               u=128 T=200 s=50 attention", 128, 200, 50, True, 20e6),
          ("cfg2           u=128 T=200 s=50", 128, 200, 50, False, 20e6),
          ("               u=64  T=200 s=50", 64, 200, 50, False, 20e6),
-         ("               u=32  T=150 s=50 (Options defaults)", 32, 150, 50, False, 20e6)]
+         ("               u=32  T=150 s=50 (Options defaults)", 32, 150, 50, False, 20e6),
+         ("               u=96  T=200 s=50", 96, 200, 50, False, 20e6),
+         ("               u=96  T=200 s=50 attention", 96, 200, 50, True, 20e6),
+         ("               u=32  T=150 s=50 attention", 32, 150, 50, True, 20e6)]
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, u, T, s, att, n in cases:
     if only not in name:
