@@ -17,6 +17,10 @@ front of the MFMA accumulating into v[88:91]).  So the build runs this audit on 
     python tools/lint_split2_isa.py <file.s> [--kernel gru_split2_kernel]
 
 A wait state = one issued instruction (`s_nop N` = N + 1), counted the way LLVM's hazard recognizer does.
+
+Two more things are audited because they once cost the kernel a fifth of its time without changing a result (item 4 of the same
+section): a `v_accvgpr_read` / `v_accvgpr_write` anywhere in the kernel (the weights are born in AGPRs and every MFMA names them there;
+the round-1 build spent 338 copies per wave-step) and any scratch (`.amdhsa_private_segment_fixed_size` / `.vgpr_spill_count` not 0).
 """
 import argparse
 import re
@@ -122,17 +126,40 @@ def audit(body):
     return hits
 
 
+def spills(path, pattern):
+    """(kernel, key, value) for every non-zero scratch / spill entry of the matching kernels' descriptors and metadata."""
+    out, cur = [], None
+    with open(path) as fh:
+        for raw in fh:
+            t = raw.strip()
+            m = re.match(r"\.amdhsa_kernel\s+(\S+)", t) or re.match(r"\.name:\s+(\S+)", t)
+            if m:
+                cur = m.group(1) if pattern in m.group(1) else None
+                continue
+            m = re.match(r"\.?(amdhsa_private_segment_fixed_size|private_segment_fixed_size:|vgpr_spill_count:|sgpr_spill_count:)\s+(\d+)", t)
+            if m and cur and int(m.group(2)) != 0:
+                out.append((cur, m.group(1).rstrip(":"), int(m.group(2))))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("asm")
     ap.add_argument("--kernel", default="gru_split2_kernel")
     a = ap.parse_args()
     total = nk = 0
+    for kern, key, val in spills(a.asm, a.kernel):
+        total += 1
+        print(f"{kern}: {key} = {val} (the kernel must not touch scratch)")
     for name, body in kernels(a.asm, a.kernel):
         nk += 1
         hits = audit(body)
         total += len(hits)
         nm = sum(1 for x in body if x.is_mfma)
+        acc = [x for x in body if x.mn.startswith("v_accvgpr")]
+        if acc:
+            total += 1
+            print(f"{name}: {len(acc)} v_accvgpr copies (first: line {acc[0].line}: {acc[0].text})")
         print(f"{name}: {len(body)} instructions, {nm} MFMAs, {len(hits)} hazard(s)")
         for kind, first, second, states in hits[:12]:
             need = STATES_VALU_TO_MFMA if kind == "A" else STATES_MFMA_TO_USE
