@@ -703,8 +703,10 @@ def test_split2_isa_lint(tmp_path):
     assert rc == 1 and "B:" in out, out
     rc, out = run([mf, "v_mfma_f32_16x16x32_f16 v[4:7], a[24:27], v[88:91], v[4:7]"])                    # result as another MFMA's B operand
     assert rc == 1 and "B:" in out, out
-    rc, out = run(["v_accvgpr_read_b32 v1, a3", "s_nop 4", mf])                                          # a compiler copy out of the weights' AGPRs
-    assert rc == 1 and "v_accvgpr" in out, out
+    rc, out = run(["v_accvgpr_read_b32 v1, a3", "s_nop 4", mf])                                          # a parked value: tolerated, reported
+    assert rc == 0 and "v_accvgpr" in out, out
+    rc, out = run(["v_accvgpr_read_b32 v1, a3"] * 17 + ["s_nop 4", mf])                                  # copies out of the weights' AGPRs wholesale
+    assert rc == 1 and "more than" in out, out
     p = tmp_path / "k.s"                                                                                  # scratch in the kernel descriptor
     p.write_text("_ZN1x17gru_split2_kernelILi0ELb1EEEv:\n\ts_endpgm\n\t.amdhsa_kernel _ZN1x17gru_split2_kernelILi0ELb1EEEv\n"
                  "\t\t.amdhsa_private_segment_fixed_size 16\n")

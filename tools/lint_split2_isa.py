@@ -19,8 +19,8 @@ front of the MFMA accumulating into v[88:91]).  So the build runs this audit on 
 A wait state = one issued instruction (`s_nop N` = N + 1), counted the way LLVM's hazard recognizer does.
 
 Two more things are audited because they once cost the kernel a fifth of its time without changing a result (item 4 of the same
-section): a `v_accvgpr_read` / `v_accvgpr_write` anywhere in the kernel (the weights are born in AGPRs and every MFMA names them there;
-the round-1 build spent 338 copies per wave-step) and any scratch (`.amdhsa_private_segment_fixed_size` / `.vgpr_spill_count` not 0).
+section): more than 16 `v_accvgpr_read` / `v_accvgpr_write` in a kernel (the weights are born in AGPRs and every MFMA names them there;
+the round-1 build spent 338 copies per wave-step; a handful is the allocator parking a value in one of the 56 free AGPRs) and any scratch (`.amdhsa_private_segment_fixed_size` / `.vgpr_spill_count` not 0).
 """
 import argparse
 import re
@@ -29,6 +29,7 @@ import sys
 REG = re.compile(r"(?<![\w.])([va])(?:\[(\d+):(\d+)\]|(\d+))(?![\w\[])")
 STATES_VALU_TO_MFMA = 2
 STATES_MFMA_TO_USE = 12
+ACC_COPIES_ALLOWED = 16
 
 
 def regs(tok):
@@ -157,9 +158,10 @@ def main():
         total += len(hits)
         nm = sum(1 for x in body if x.is_mfma)
         acc = [x for x in body if x.mn.startswith("v_accvgpr")]
-        if acc:
-            total += 1
-            print(f"{name}: {len(acc)} v_accvgpr copies (first: line {acc[0].line}: {acc[0].text})")
+        if acc:                                                    # a handful = the allocator parking a value in a free AGPR; the pathology is hundreds
+            bad = len(acc) > ACC_COPIES_ALLOWED
+            total += 1 if bad else 0
+            print(f"{name}: {len(acc)} v_accvgpr copies{' (more than ' + str(ACC_COPIES_ALLOWED) + ')' if bad else ' (tolerated)'}, first: line {acc[0].line}: {acc[0].text}")
         print(f"{name}: {len(body)} instructions, {nm} MFMAs, {len(hits)} hazard(s)")
         for kind, first, second, states in hits[:12]:
             need = STATES_VALU_TO_MFMA if kind == "A" else STATES_MFMA_TO_USE
