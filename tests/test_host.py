@@ -712,3 +712,22 @@ def test_split2_isa_lint(tmp_path):
                  "\t\t.amdhsa_private_segment_fixed_size 16\n")
     r = subprocess.run([sys.executable, tool, str(p)], capture_output=True, text=True)
     assert r.returncode == 1 and "scratch" in r.stdout, r.stdout
+
+
+def test_split2_schedule_is_the_generators_default(tmp_path):
+    """deepgrp_amd/csrc/gru_split2_phase.inc is generated and checked in: it must be what tools/gen_split2_schedule.py writes with its
+    defaults (a hand edit, or a generator change without regenerating, would go unnoticed otherwise), with all 150 MFMAs of a phase in
+    program order and the barrier behind every publish link."""
+    import subprocess
+    out = tmp_path / "phase.inc"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_split2_schedule.py"), "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = out.read_text().splitlines()[1:]                  # (the first line records the path-independent arguments; compare all the same)
+    have = open(os.path.join(ROOT, "deepgrp_amd", "csrc", "gru_split2_phase.inc")).read().splitlines()[1:]
+    assert have == want
+    body = " ".join(have)
+    mk = re.findall(r"M_K\((\d), (\d+)\)", body)
+    assert mk == [(str(ks), str(n)) for ks in range(4) for n in range(36)] and len(re.findall(r"M_D\(\d\)", body)) == 6
+    assert all(body.index(f"PB({g}, 4)") < body.index("BAR") for g in range(4)) and body.index("BAR") < body.index("RD0")
+    for e in range(16):                                       # a sub-tile's accumulators restart only behind its chains' last reads of them
+        assert body.index(f"G({e}, 4)") < body.index(f"CI(0, {e // 4})")
