@@ -1158,6 +1158,18 @@ static size_t gru_tile_carve(const dgrp_model *m, gru_params &p, int mode, int64
     p.lo_tile_off = (int)dgrp_align_up(fixed + (int64_t)p.ospan * m->C * 4, 16);
     return split ? (size_t)p.lo_tile_off + lo_tiles : (size_t)fixed + (size_t)p.ospan * m->C * 4;
 }
+// LDS a one-tile workgroup may carve (the fixed part, then as many rows of the merged-output image as fit; windows whose rows
+// do not fit go to HBM with atomics of their own: the result is the same bit for bit).  The registers allow two waves per SIMD, i.e.
+// 8 / NW workgroups per CU -- the image must not be what keeps them out: with 72 KiB a 32-unit model ran two of its eight
+// workgroups per CU's worth of LDS (2 300 -> 2 930 Mbp/s with 19 KiB), a 64-unit split-operand model three of four (1 120 -> 1 210
+// with 39 KiB; its fp16-operand kernel is 1 % better off with the larger image).  Five waves and more: one workgroup per CU.
+static int64_t tile_budget(const dgrp_model *m, bool split)
+{
+    if (const char *e = getenv("DGRP_TILE_BUDGET_KB")) return (int64_t)atoi(e) * 1024;
+    if (m->NW == 1) return 19 * 1024;
+    if (m->NW == 2 && split) return 39 * 1024;
+    return (m->NW > 4 ? 144 : 72) * 1024;
+}
 // gru_split2_kernel (gru_split2.hip): two tile carves with row pitch UP + 16, then the input-projection table
 #define DGRP_SPLIT2_PAD 16
 #define DGRP_SPLIT2_XTAB_BYTES (5 * (4 * 128 * 4 + 32))
@@ -1200,8 +1212,8 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
             return dgrp_split2_launch(p, groups, half_bytes, m->onercp != 0, stream);
         }
     }
-    // rows spanned by 16 consecutive windows, capped so that two workgroups fit a CU's 160 KiB (NW > 4: one workgroup per CU anyway)
-    const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, (m->NW > 4 ? 144 : 72) * 1024);
+    // rows spanned by 16 consecutive windows, capped so that the workgroups the registers allow fit a CU's 160 KiB (tile_budget)
+    const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, tile_budget(m, split));
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T,
                  gru_lds_seq(p.Tp));
     if (split && m->d_stream) return dgrp_stream_launch(p, m->cell, m->NW, groups, lds, stream);
@@ -1276,7 +1288,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
             return dgrp_split2_launch(p, total_groups, half_bytes, m->onercp != 0, stream);
         }
     }
-    const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, (m->NW > 4 ? 144 : 72) * 1024);
+    const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, tile_budget(m, split));
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T,
                  gru_lds_seq(p.Tp));
     if (split && m->d_stream) return dgrp_stream_launch(p, m->cell, m->NW, total_groups, lds, stream);
