@@ -736,7 +736,8 @@ __device__ __forceinline__ float wave_allsum(float x)
 //             more pair sums;
 //   softmax   over t kept online across tiles (running max / sum, context rescaled per tile), wave reductions by DPP + readlane;
 //   context   ctx[j] += p[t] a[t, j] with p[t] read from the lane that holds it (v_readlane: a scalar operand of the fma).
-// Then ctx . W_top by lane shares + wave sums, and the output rows as in the tile kernel.
+// Then ctx . W_top by lane shares + wave sums; the output rows of the workgroup's four windows pre-merge in an LDS image (they
+// overlap by T - s rows each) that is flushed with one atomic per non-zero entry (u = 128: +2 %, with the fp16 spill +7 %).
 // ------------------------------------------------------------------------------------------
 template <typename AT, int EPL, int TT>
 __global__ void __launch_bounds__(256, 3) attention_row_kernel(const att_params p)
@@ -744,9 +745,22 @@ __global__ void __launch_bounds__(256, 3) attention_row_kernel(const att_params 
     constexpr int LT = TT == 32 ? 5 : TT == 16 ? 4 : TT == 8 ? 3 : 2, SH = 6 - LT;    // a tile's step t ends up in the 2^SH lanes t << SH ..
     struct alignas(sizeof(AT) * EPL) row_t { AT v[EPL]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t wl = (int64_t)blockIdx.x * 4 + wave;
-    if (wl >= p.nw) return;                                   // (no barrier anywhere below)
+    const int64_t wl_ = (int64_t)blockIdx.x * 4 + wave;
+    const bool alive = wl_ < p.nw;                             // (a wave without a window walks the last one and emits nothing)
+    const int64_t wl = alive ? wl_ : p.nw - 1;
     const int T = p.T, UP = p.UP, C = p.C;
+    // merge: the rows the workgroup's four windows cover pre-merge in an LDS image (they overlap by T - s rows each), flushed once
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_row_dyn[];
+    unsigned *obuf = reinterpret_cast<unsigned *>(att_row_dyn);
+    int64_t img_lo = 0;
+    const bool image = p.merge && p.ospan > 0 && !p.recs;
+    if (image) {
+        const int64_t w_first = (int64_t)blockIdx.x * 4, w_last = min(w_first + 3, p.nw - 1);
+        const int64_t a = dgrp_place_row(p.place, p.w0 + w_first, p.s), b = dgrp_place_row(p.place, p.w0 + w_last, p.s);
+        img_lo = a < b ? a : b;
+        for (int i = threadIdx.x; i < p.ospan * C; i += 256) obuf[i] = 0u;
+        __syncthreads();
+    }
     const int k0 = lane * EPL;
     const bool on = k0 < UP;                                  // UP / EPL lanes carry units
     const AT *avg = reinterpret_cast<const AT *>(p.avg) + wl * (int64_t)T * UP + (on ? k0 : 0);
@@ -826,8 +840,10 @@ __global__ void __launch_bounds__(256, 3) attention_row_kernel(const att_params 
     }
     int64_t limit = p.n;
     const int64_t row0 = p.merge ? att_window_row(p, wl, &limit) : wl * (int64_t)T;
+    const int64_t ioff = row0 - img_lo;                       // the window's first row in the image, if it lies inside
+    const bool in_image = image && ioff >= 0 && ioff + T <= p.ospan;
     const float *pl = p.pl + wl * (int64_t)T * C;
-    for (int t = lane; t < T; t += 64) {
+    for (int t = lane; t < T && alive; t += 64) {
         float lg[16];
         float mx = -INFINITY;
 #pragma unroll
@@ -841,12 +857,23 @@ __global__ void __launch_bounds__(256, 3) attention_row_kernel(const att_params 
         for (int c = 0; c < 16; ++c)
             if (c < C) {
                 const float v = lg[c] / den;
-                if (p.merge) {
+                if (in_image) {
+                    lds_atomic_max(obuf + (ioff + t) * C + c, __float_as_uint(v));
+                } else if (p.merge) {
                     if (row0 + t < limit) atomicMax(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
                 } else {
                     p.out[(row0 + t) * C + c] = v;
                 }
             }
+    }
+    if (image) {
+        __syncthreads();
+        unsigned *gout = reinterpret_cast<unsigned *>(p.out) + img_lo * C;
+        const int64_t lim = (p.n - img_lo) * C;
+        for (int i = threadIdx.x; i < p.ospan * C; i += 256) {
+            const unsigned v = obuf[i];
+            if (v != 0u && i < lim) global_atomic_max(gout + i, v);
+        }
     }
 }
 
@@ -1369,12 +1396,16 @@ int dgrp_attention_launch_recs(const dgrp_model *m, int64_t s, dgrp_placement pl
     }
     // 65-256 units: one wave per window straight from HBM (attention_row_kernel), 2 units per lane up to 128 units, 4 beyond
     const unsigned rgrid = (unsigned)((nw + 3) / 4);
+    // merge: the rows four consecutive windows cover, as an LDS image (if they fit 48 KiB; batched records: rows of different records)
+    const int64_t span = 3 * s + m->T;
+    p.ospan = merge && !d_recs && span * m->C * 4 <= 48 * 1024 ? (int)span : 0;
+    const size_t rdyn = (size_t)p.ospan * m->C * 4;
     if (m->UP <= 128) {
-        if (f32) hipLaunchKernelGGL((attention_row_kernel<float, 2, 8>), dim3(rgrid), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attention_row_kernel<_Float16, 2, 4>), dim3(rgrid), dim3(256), 0, stream, p);
+        if (f32) hipLaunchKernelGGL((attention_row_kernel<float, 2, 8>), dim3(rgrid), dim3(256), rdyn, stream, p);
+        else hipLaunchKernelGGL((attention_row_kernel<_Float16, 2, 4>), dim3(rgrid), dim3(256), rdyn, stream, p);
     } else {
-        if (f32) hipLaunchKernelGGL((attention_row_kernel<float, 4, 8>), dim3(rgrid), dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attention_row_kernel<_Float16, 4, 8>), dim3(rgrid), dim3(256), 0, stream, p);
+        if (f32) hipLaunchKernelGGL((attention_row_kernel<float, 4, 8>), dim3(rgrid), dim3(256), rdyn, stream, p);
+        else hipLaunchKernelGGL((attention_row_kernel<_Float16, 4, 8>), dim3(rgrid), dim3(256), rdyn, stream, p);
     }
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
