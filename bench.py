@@ -21,8 +21,12 @@ Prints ONE JSON line (rank 0):
   accuracy              the timed kernel against the plain-fp32 kernels on windows spread over the chromosome
   fast_mode             for information: the fp16-operand kernel (`--fast`) on the same input, and its accuracy
   cpu_baseline          the CPU restatement of the same path (oracle/) on bounded samples: all host threads, and one thread
-                        (the reference's default --threads 1)
-(stages, e2e, accuracy, fast_mode and cpu_baseline at N = 1 only.)
+                        (the reference's default --threads 1); rank 0, at N > 1 after the process group is gone
+  ranks                 N > 1: what every rank saw -- its GPU (PCI bus id, uuid), its step and kernel times, its rows (all_gather)
+  sharded_file          N > 1: ONE FASTA file of N records through the command line's sharded path (deepgrp_amd/__main__.py:
+                        chunk table from per-rank host scans, records shared out by byte length, rank-local upload + ingest,
+                        RCCL gather of the rows, rank 0 writes the TSV), with the bytes every rank uploaded
+(stages, e2e, accuracy and fast_mode at N = 1 only.)
 """
 import argparse
 import json
@@ -56,6 +60,7 @@ def parse_args():
     ap.add_argument("--accuracy-windows", type=int, default=4096, help="windows compared with the fp32 yardstick after the run (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py starts the ranks itself")
+    ap.add_argument("--no-sharded-file", action="store_true", help="N > 1: skip the sharded command-line leg")
     return ap.parse_args()
 
 
@@ -95,6 +100,98 @@ def cpu_baseline(weights, sample_bp: int):
             "sample": f"{sample_bp} bp synthetic contig, full path (oracle/dgrp_oracle.c, float32, OpenMP over windows), "
                       f"{dt:.1f} s, {nrows} rows",
             "one_thread": {"value": round(one_bp / dt1 / 1e6, 6), "unit": "Mbp/s", "sample": f"{one_bp} bp, {dt1:.1f} s"}}
+
+
+def write_fasta(path, header: bytes, raw: bytes) -> None:
+    """One record, 60-column lines."""
+    import numpy as np
+    body = np.frombuffer(raw, np.uint8)
+    full = body.size // 60 * 60
+    lines = np.empty((full // 60, 61), np.uint8)
+    lines[:, :60] = body[:full].reshape(-1, 60)
+    lines[:, 60] = 10
+    with open(path, "wb") as fh:
+        fh.write(b">" + header + b"\n")
+        fh.write(lines.tobytes())
+        if body.size > full:
+            fh.write(body[full:].tobytes() + b"\n")
+
+
+def gpu_identity(torch, dev) -> dict:
+    """What tells two GPUs apart: PCI bus id and uuid of the device this rank runs on."""
+    prop = torch.cuda.get_device_properties(dev)
+    out = {"device": int(dev.index), "name": prop.name}
+    try:
+        out["pci_bus_id"] = "%04x:%02x:%02x.0" % (prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id)
+    except AttributeError:
+        out["pci_bus_id"] = None
+    try:
+        out["uuid"] = str(prop.uuid)
+    except AttributeError:
+        out["uuid"] = None
+    return out
+
+
+def sharded_file_leg(args, rank, world, raw, weights, n_bases, dist, torch):
+    """ONE FASTA file holding every rank's chromosome, through `deepgrp predict` in-process on all ranks (the sharded path of
+    deepgrp_amd/__main__.py): per-rank chunk scan -> LPT by byte length -> rank-local upload + device ingest -> the step ->
+    record gather -> rank 0 writes the TSV.  Timed between barriers on the second of two runs."""
+    from deepgrp_amd import fasta as dgfasta, model as dgmodel
+    from deepgrp_amd.__main__ import CommandLineParser, main as cli_main
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    tag = os.environ.get("MASTER_PORT", "0")
+    part = os.path.join(shm, f"dgrp_bench_{tag}_part{rank}.fa")
+    fa_path = os.path.join(shm, f"dgrp_bench_{tag}_all.fa")
+    mpath = os.path.join(shm, f"dgrp_bench_{tag}_model.hdf5")
+    tsv = os.path.join(shm, f"dgrp_bench_{tag}_out.tsv")
+    try:
+        write_fasta(part, b"chr_rank%d" % rank, raw)
+        dist.barrier()
+        if rank == 0:
+            import shutil
+            with open(fa_path, "wb") as dst:
+                for r in range(world):
+                    with open(os.path.join(shm, f"dgrp_bench_{tag}_part{r}.fa"), "rb") as src:
+                        shutil.copyfileobj(src, dst, 16 << 20)
+            dgmodel.save_keras_hdf5(mpath, weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
+                                    weights["ff_bias"], weights["scale"], vecsize=T)
+        dist.barrier()
+        os.unlink(part)
+        argv = ["-b", str(BATCH), "-s", str(STEP), "-x", str(XDROP), "-l", str(MIN_MSS), "predict", mpath, fa_path, "--output", tsv]
+        if args.fast:
+            argv.append("--fast")
+        times = []
+        for _ in range(2):
+            up0 = dgfasta.UPLOAD_STATS["bytes"]
+            dist.barrier()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            cli_main(argv)                                  # ends with a barrier of its own (rank 0 has written the file)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t)
+        stats = [None] * world
+        dist.all_gather_object(stats, {"rank": rank, "uploaded_bytes": dgfasta.UPLOAD_STATS["bytes"] - up0,
+                                       "records": CommandLineParser.last_sharded.get("records"), "s": round(times[-1], 4)})
+        if rank != 0:
+            return None
+        file_bytes = os.path.getsize(fa_path)
+        dt = max(x["s"] for x in stats)
+        with open(tsv, "rb") as fh:
+            rows_out = fh.read().count(b"\n")
+        return {"value": round(n_bases * world / dt / 1e6, 3), "unit": "Mbp/s (whole job)", "ms": round(dt * 1e3, 3),
+                "file_bytes": int(file_bytes), "records": world, "rows_out": int(rows_out),
+                "uploaded_bytes_per_rank": [x["uploaded_bytes"] for x in stats], "records_per_rank": [x["records"] for x in stats],
+                "what": "deepgrp predict <model.hdf5> <one FASTA file of N records> --output <tsv> on N ranks: model load, per-rank chunk "
+                        "scan, rank-local upload + device ingest of the rank's byte ranges only, the step, RCCL gather of the rows, "
+                        "TSV written by rank 0; second of two runs"}
+    finally:
+        dist.barrier()
+        if rank == 0:
+            for f in (fa_path, mpath, tsv):
+                if os.path.exists(f):
+                    os.unlink(f)
+        if os.path.exists(part):
+            os.unlink(part)
 
 
 def main():
@@ -173,7 +270,7 @@ def main():
     for _ in range(args.steps):
         nrows = len(step())
     fence()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     kern_ms, kern_launches, kern_windows = kernel_timer_read()
     check(L.dgrp_kernel_timer_enable(0), "dgrp_kernel_timer_enable")
     if world > 1:
@@ -214,18 +311,8 @@ def main():
         from deepgrp_amd.runner import RecordRunner, rows_text, rows_text_batch
         shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
         fa_path = os.path.join(shm, f"dgrp_bench_{os.getpid()}.fa")
-        body = np.frombuffer(raw, np.uint8)
-        full = body.size // 60 * 60
-        lines = np.empty((full // 60, 61), np.uint8)
-        lines[:, :60] = body[:full].reshape(-1, 60)
-        lines[:, 60] = 10
         try:
-            with open(fa_path, "wb") as fh:
-                fh.write(b">chr_bench\n")
-                fh.write(lines.tobytes())
-                if body.size > full:
-                    fh.write(body[full:].tobytes() + b"\n")
-            del lines
+            write_fasta(fa_path, b"chr_bench", raw)
             fasta_bytes = os.path.getsize(fa_path)
 
             def file_to_tsv():
@@ -267,18 +354,31 @@ def main():
             other = {"value": round(n_bases / dt_o / 1e6, 3), "unit": "Mbp/s (1 GPU, this rank)", "ms_per_step": round(dt_o * 1e3, 3),
                      "kernel_ms": round(ms_o / max(launches_o, 1), 3), "rows_out": int(len(rows_o))}
 
+    # ---- N > 1: what every rank saw (the evidence that N distinct GPUs did the work), then the sharded command-line leg
+    ranks_block = sharded = None
+    if world > 1:
+        me = dict(rank=rank, **gpu_identity(torch, dev), ms_per_step=round(dt_local / args.steps * 1e3, 3),
+                  mbp_per_s=round(n_bases * args.steps / dt_local / 1e6, 3), kernel_ms=round(avg_ms, 3),
+                  kernel_launches=int(kern_launches), rows=int(local_rows[0]), host=os.uname().nodename, pid=os.getpid())
+        ranks_block = [None] * world
+        dist.all_gather_object(ranks_block, me)
+        if not args.no_sharded_file:
+            sharded = sharded_file_leg(args, rank, world, raw, weights, n_bases, dist, torch)
+
     # HBM traffic of the timed kernel from the PMC passes of profiles/ (separate rocprofv3 --pmc runs of this command;
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), scaled to this launch size
     fused_name = "gru_fused_kernel<4, 0, %s>" % ("true" if model.kernel_flags & 1 else "false")
     split_name = "gru_split2_kernel<0, %s>" % ("true" if model.kernel_flags & 1 else "false")
     kernel_name = fused_name if not pipe.split else split_name
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_gru_traffic.json")
-    if os.path.exists(tpath) and args.weights == "trained":
-        with open(tpath) as fh:
+    traffic = traffic_source = None
+    tfiles = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_gru_traffic.json")) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if tfiles and args.weights == "trained":
+        with open(os.path.join(ROOT, "profiles", tfiles[-1])) as fh:
             per_kernel = json.load(fh).get("kernels", {}).get(kernel_name.split("<")[0])
         if per_kernel:
             traffic = round(per_kernel["hbm_bytes_per_window"] * win_per_launch)
+            traffic_source = (f"profiles/{tfiles[-1]}: a STORED per-window figure from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                              "command (2*FETCH + WRITE, gfx950 correction), scaled to this launch's windows -- not a counter of this run")
     if rank == 0:
         value = n_bases * world * args.steps / dt / 1e6
         cfg = "configs[2]" if abs(args.mbp - 250) < 1e-9 else "configs[1]" if abs(args.mbp - 50) < 1e-9 else "custom size"
@@ -298,6 +398,7 @@ def main():
                        "rows_out": int(nrows), "parallelism": f"contig-sharded x{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "kernel": kernel_name, "flop_per_window": FLOP_PER_WINDOW, "avg_launch_ms": round(avg_ms, 3),
                          "windows_per_launch": int(win_per_launch), "launches_timed": int(kern_launches),
                          "timing": "HIP events recorded by the library around each launch on its stream inside the timed steps (dgrp_kernel_timer_*)"},
@@ -322,12 +423,20 @@ def main():
             if args.accuracy_windows > 0 and extras:
                 other["accuracy"] = acc_obj(model.check_accuracy(d_idx, STEP, args.accuracy_windows, level=0 if pipe.split else 1))
             out["fast_mode" if pipe.split else "default_mode"] = other
-        if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample_bp)
-        print(json.dumps(out), flush=True)
+        if ranks_block is not None:
+            out["ranks"] = ranks_block
+            out["distinct_gpus"] = len({(r["host"], r["pci_bus_id"] or r["uuid"] or r["device"]) for r in ranks_block})
+        if sharded is not None:
+            out["sharded_file"] = sharded
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the CPU leg needs no other rank and no collective: at N > 1 it runs after the process group is gone (the other ranks have
+        # left; nobody waits in a barrier while the host cores are busy)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(weights, args.cpu_sample_bp)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -26,21 +26,10 @@ _LOG = logging.getLogger(__name__)
 def _read_multi_fasta(filestream: TextIO) -> Iterator[Tuple[str, str]]:
     """Reads a multi FASTA file (deepgrp/__main__.py:20-43): header = text after '>', sequence
     lines upper-cased and joined; a record without header is dropped; a blank line raises
-    IndexError exactly like `line[0]` does in the reference."""
+    IndexError exactly like `line[0]` does in the reference.  (The loop itself: fasta.LineLoop.)"""
+    from .fasta import read_multi_fasta_lines
     _LOG.debug("Reading FASTA file.")
-    header = ""
-    sequence: List[str] = []
-    for line in filestream:
-        line = line.strip()
-        if line[0] == ">":
-            if header:
-                yield header, "".join(sequence)
-            header = line[1:]
-            sequence = []
-        else:
-            sequence.append(line.upper())
-    if header:
-        yield header, "".join(sequence)
+    yield from read_multi_fasta_lines(filestream)
 
 
 def _predict(dnasequence: str, model, options, step_size: int, use_mss: bool) -> Tuple[np.ndarray, int]:
@@ -165,11 +154,18 @@ class CommandLineParser:
 
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
+        backend = dist.get_backend() if dist.is_initialized() else os.environ.get("DGRP_DIST_BACKEND", "nccl")
         if torch.cuda.is_available():
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            local_rank, ndev = int(os.environ.get("LOCAL_RANK", "0")), torch.cuda.device_count()
+            if local_rank >= ndev and backend != "gloo":       # (gloo: several ranks may share a GPU -- rehearsals on one card)
+                sys.exit(f"rank {rank}: local rank {local_rank} but only {ndev} GPUs visible")
+            torch.cuda.set_device(local_rank % max(ndev, 1))
         if world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(os.environ.get("DGRP_DIST_BACKEND", "nccl"))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+            else:
+                dist.init_process_group(backend)
 
         if getattr(args, "precise", False) and getattr(args, "fast", False):
             sys.exit("--precise and --fast exclude each other")
@@ -228,15 +224,14 @@ class CommandLineParser:
                     for kind, key, rows in runner.results(records_of(filename)):
                         outstream.write(rows_text_batch(filename, key, rows) if kind == "batch" else rows_text(filename, key, rows))
             else:
-                # contig sharding: every rank parses the (small) index of records, runs its share, rank 0 writes
-                records = []
-                for filename in args.FASTA:
-                    for header, rec in records_of(filename):
-                        records.append((filename, header, rec))
-                length = lambda r: r.d_idx.numel() if isinstance(r, DeviceRecord) else len(r)
-                from .distributed import raise_together, run_split
+                from .distributed import run_split
                 if getattr(args, "split_contigs", False):
-                    # every record over all ranks (distributed.run_split); errors are per record and hit every rank alike
+                    # every record over all ranks (distributed.run_split): every rank holds every record's class indices and takes
+                    # its share of the windows; errors are per record and hit every rank alike
+                    records = []
+                    for filename in args.FASTA:
+                        for header, rec in records_of(filename):
+                            records.append((filename, header, rec))
                     parts = []
                     for i, (_f, _h, rec) in enumerate(records):
                         if isinstance(rec, DeviceRecord):
@@ -247,28 +242,100 @@ class CommandLineParser:
                             startpos, d_idx = upload_sequence(rec.encode("utf-8"))
                         parts.append(run_split(pipe, d_idx, startpos, i))
                     allrows = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
+                    if rank == 0:
+                        for i, (filename, header, _seq) in enumerate(records):
+                            outstream.write(rows_text(filename, header, allrows[allrows["contig"] == i]))
                 else:
-                    mine = shard_contigs([length(r[2]) for r in records], world)[rank]
-                    # this rank's share through the same pool / batching as the single-process path, keyed by record index
-                    parts, failure = [], None
-                    try:
-                        for kind, key, rows in runner.results((i, records[i][2]) for i in mine):
-                            rows["contig"] = np.asarray(key, np.int32)[rows["contig"]] if kind == "batch" else key
-                            parts.append(rows)
-                    except Exception as e:                  # noqa: BLE001 -- re-raised on every rank together, below
-                        failure = e
-                    raise_together(failure)                 # a record that raises (all-N ...) must not leave the others in the gather
-                    local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
-                    allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
-                if rank == 0:
-                    for i, (filename, header, _seq) in enumerate(records):
-                        outstream.write(rows_text(filename, header, allrows[allrows["contig"] == i]))
+                    CommandLineParser._predict_sharded(args, runner, records_of, outstream)
                 dist.barrier()
         finally:
             # rows already produced reach the file even when a later record raises (the reference leaves that to
             # interpreter shutdown)
             if rank == 0 and args.output != "-":
                 outstream.close()
+
+    @staticmethod
+    def _predict_sharded(args, runner, records_of, outstream) -> None:
+        """Records sharded over the ranks (the reference's record loop, deepgrp/__main__.py:275-292, carries no state from one
+        record to the next).  Ingest is rank-local: the chunk table of every FASTA file comes from host scans of 1/world of its
+        bytes per rank, the chunks are shared out longest-first by byte length (runs of short records travel together), and a
+        rank reads, uploads and encodes ONLY the byte ranges of its share.  Rank 0 gathers the 24-byte segment records (RCCL)
+        and writes them in input order.  Inputs that are not regular FASTA files (stdin, .npz) are parsed by every rank and
+        shared out as whole records."""
+        import torch
+        import torch.distributed as dist
+
+        from . import fasta
+        from .distributed import file_chunk_tables, gather_records, plan_file_shares, raise_together
+        from .fasta import DeviceRecord
+        from .pipeline import SEGMENT_DTYPE
+        from .runner import rows_text_batch
+        world, rank = dist.get_world_size(), dist.get_rank()
+        files = list(args.FASTA)
+        sharded = [i for i, f in enumerate(files) if f != "-" and os.path.isfile(f) and not f.endswith(".npz")]
+        parsed = []                                        # (file index, record number, header, record), the same on every rank
+        for i, f in enumerate(files):
+            if i not in sharded:
+                parsed += [(i, j, header, rec) for j, (header, rec) in enumerate(records_of(f))]
+        length = lambda r: max(r.length, 0) if isinstance(r, DeviceRecord) else len(r)
+        tables = file_chunk_tables([files[i] for i in sharded])
+        sizes = [os.path.getsize(files[i]) for i in sharded]
+        ranges, extras = plan_file_shares(tables, sizes, [length(p[3]) for p in parsed], world)
+        uploaded0 = fasta.UPLOAD_STATS["bytes"]
+
+        def my_records():
+            work = {}
+            for f, a, b in ranges[rank]:
+                work.setdefault(sharded[f], []).append((a, b))
+            for i in extras[rank]:
+                work.setdefault(parsed[i][0], []).append(parsed[i])
+            for fi in sorted(work):
+                if fi in sharded:
+                    for key, header, rec in fasta.ingest_ranges(files[fi], work[fi]):
+                        yield ((fi, key), header), rec
+                else:
+                    for _fi, j, header, rec in work[fi]:
+                        yield ((fi, (j, 0)), header), rec
+
+        entries, parts, failure = [], [], None           # entries[local id] = (key, header)
+        try:
+            for kind, key, rows in runner.results(my_records()):
+                if kind == "batch":
+                    rows["contig"] += len(entries)
+                    entries += key
+                else:
+                    rows["contig"] = len(entries)
+                    entries.append(key)
+                parts.append(rows)
+        except Exception as e:                  # noqa: BLE001 -- re-raised on every rank together, below
+            failure = e
+        raise_together(failure)                 # a record that raises (all-N ...) must not leave the others in the gather
+        every = [None] * world
+        dist.all_gather_object(every, entries)
+        order = sorted((key, r, lid) for r, ents in enumerate(every) for lid, (key, _h) in enumerate(ents))
+        gid = np.zeros(max(len(entries), 1), np.int32)
+        for g, (_key, r, lid) in enumerate(order):
+            if r == rank:
+                gid[lid] = g
+        local = np.concatenate(parts) if parts else np.zeros(0, SEGMENT_DTYPE)
+        local["contig"] = gid[local["contig"]]
+        allrows = gather_records(local, torch.device("cuda", torch.cuda.current_device()))
+        CommandLineParser.last_sharded = {"uploaded_bytes": fasta.UPLOAD_STATS["bytes"] - uploaded0, "records": len(entries),
+                                          "file_bytes": int(sum(sizes))}
+        _LOG.info("rank %d: %d records, %d of %d file bytes uploaded", rank, len(entries),
+                  CommandLineParser.last_sharded["uploaded_bytes"], int(sum(sizes)))
+        if rank == 0:
+            g = 0
+            while g < len(order):                          # one formatter call per input file
+                fi, g0 = order[g][0][0], g
+                while g < len(order) and order[g][0][0] == fi:
+                    g += 1
+                lo, hi = np.searchsorted(allrows["contig"], [g0, g])
+                rows = allrows[lo:hi].copy()
+                rows["contig"] -= g0
+                outstream.write(rows_text_batch(files[fi], [every[r][lid][1] for _k, r, lid in order[g0:g]], rows))
+
+    last_sharded: dict = {}
 
     @staticmethod
     def verify(args: argparse.Namespace, options) -> None:

@@ -26,6 +26,72 @@ def shard_contigs(lengths: Sequence[int], world_size: int) -> List[List[int]]:
     return [sorted(x) for x in out]
 
 
+def lpt(weights: Sequence[int], world_size: int) -> List[List[int]]:
+    """Longest-processing-time-first: item indices per rank (input order inside a rank), deterministic."""
+    return shard_contigs(weights, world_size)
+
+
+def file_chunk_tables(paths: Sequence[str]) -> List[np.ndarray]:
+    """Chunk starts (fasta.chunk_starts_host) of every file, on every rank, with each rank scanning 1/world of each file's bytes on
+    its host and the lists exchanged (all_gather_object: a few bytes per record)."""
+    import os
+
+    from .fasta import chunk_starts_host
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    mine = []
+    for path in paths:
+        size = os.path.getsize(path)
+        mine.append(chunk_starts_host(path, rank * size // world, (rank + 1) * size // world))
+    if world == 1:
+        return mine
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    return [np.concatenate([parts[r][f] for r in range(world)]) for f in range(len(paths))]
+
+
+def plan_file_shares(tables: Sequence[np.ndarray], sizes: Sequence[int], extra: Sequence[int], world: int, pieces: int = 8):
+    """Which bytes of which file every rank ingests (deepgrp/__main__.py:275-292 of the reference: records are independent).
+    `tables[f]` = chunk starts of file f, `sizes[f]` its bytes.  Chunks are work items of their byte length; runs of short chunks
+    (files of thousands of contigs) travel together so that a rank's share stays a few contiguous ranges; `extra` are further
+    items (records that were parsed on the host: stdin, .npz) by their lengths.  Longest-processing-time-first over all items.
+    Returns (per rank [(file, a, b), ...] sorted and coalesced, per rank [extra index, ...])."""
+    total = int(sum(sizes)) + int(sum(extra))
+    target = max(total // max(world * pieces, 1), 1)
+    items: List[Tuple[int, int, int]] = []          # (file, a, b)
+    for f, (starts, size) in enumerate(zip(tables, sizes)):
+        edges = [int(x) for x in starts] + [int(size)]
+        run_a = None
+        for a, b in zip(edges[:-1], edges[1:]):
+            if b - a >= target:
+                if run_a is not None:
+                    items.append((f, run_a, a))
+                    run_a = None
+                items.append((f, a, b))
+            else:
+                if run_a is None:
+                    run_a = a
+                if b - run_a >= target:
+                    items.append((f, run_a, b))
+                    run_a = None
+        if run_a is not None:
+            items.append((f, run_a, edges[-1]))
+    weights = [b - a for _f, a, b in items] + [int(x) for x in extra]
+    shares = lpt(weights, world)
+    ranges, extras = [], []
+    for share in shares:
+        mine = sorted(items[i] for i in share if i < len(items))
+        merged: List[Tuple[int, int, int]] = []
+        for f, a, b in mine:
+            if merged and merged[-1][0] == f and merged[-1][2] == a:
+                merged[-1] = (f, merged[-1][1], b)
+            else:
+                merged.append((f, a, b))
+        ranges.append(merged)
+        extras.append([i - len(items) for i in share if i >= len(items)])
+    return ranges, extras
+
+
 def gather_records(local: np.ndarray, device: torch.device) -> np.ndarray:
     """Concatenate every rank's SEGMENT_DTYPE records on rank 0 (other ranks get an empty
     array), ordered by (contig tag, start): all_gather of the counts, then one padded
@@ -131,7 +197,7 @@ def split_plan(n: int, T: int, step: int, batch: int, world: int):
     nfull, r = divmod(nwin, batch)
     first_short = nfull * batch
     shares = [window_share(first_short, world, k) for k in range(world)]
-    starts = [a * step for a, _b in shares]
+    starts = [min(a * step, n) for a, _b in shares]         # step > T: a trailing rank without windows starts (and ends) at n
     owned = [(0 if k == 0 else starts[k], n if k == world - 1 else starts[k + 1]) for k in range(world)]
     short = (nfull * r * step, min((nfull * r + r - 1) * step + T, n)) if r else (0, 0)
     return nwin, first_short, shares, owned, short

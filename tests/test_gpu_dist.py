@@ -93,13 +93,18 @@ def test_split_contigs_ranks_on_one_gpu(tmp_path, kind, world):
 def _shard_worker(rank, world, port, fasta, model, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       DGRP_DIST_BACKEND="gloo")
-    from deepgrp_amd.__main__ import main
-    main(["-b", "7", "predict", model, fasta, "--output", out])
+    import json
+    from deepgrp_amd.__main__ import CommandLineParser, main
+    main(["-b", "7", "predict", model] + fasta.split(",") + ["--output", out])
+    with open(f"{out}.rank{rank}.json", "w") as fh:
+        json.dump(CommandLineParser.last_sharded, fh)
 
 
 def test_contig_sharding_two_ranks_many_records(tmp_path):
-    """Contig sharding with 2 ranks (both on GPU 0, gloo transport) over a file of 300 short and 2 longer records: every
-    rank batches its share (dgrp_predict_batch), rank 0 gathers; TSV byte-identical to the single-process run."""
+    """Contig sharding with 2 ranks (both on GPU 0, gloo transport) over a file of 300 short and 2 longer records plus a second
+    file with records that need the reference's line loop: every rank ingests ONLY its byte ranges (about half of the bytes each,
+    all of them once between the two), batches its share (dgrp_predict_batch), rank 0 gathers; TSV byte-identical to the
+    single-process run."""
     import torch.multiprocessing as mp
     from deepgrp_amd import model as dgmodel, synthetic
     from deepgrp_amd.__main__ import main
@@ -117,19 +122,32 @@ def test_contig_sharding_two_ranks_many_records(tmp_path):
             seq = raw[pos:pos + n]
             pos += n
             fh.write(b">r%d\n" % k + b"\n".join(seq[i:i + 70] for i in range(0, len(seq), 70)) + b"\n")
+    odd = tmp_path / "odd.fa"
+    body = raw[pos:pos + 40_000]
+    with open(odd, "wb") as fh:
+        fh.write(b"ACGT\nheaderless lines are dropped\n")                                       # a first chunk without '>'
+        fh.write(b">crlf\r\n" + b"\r\n".join(body[i:i + 60] for i in range(0, 9000, 60)) + b"\r\n")
+        fh.write(b">spaces inside\n" + b"\n".join(body[i:i + 50] + b"  " for i in range(9000, 15000, 50)) + b"\n")   # reference loop
+        fh.write(b">lower\n" + body[15000:30000].lower() + b"\n>\nACGTACGT\n>empty\n>last\n" + body[30000:] + b"\n")
     single = str(tmp_path / "single.tsv")
-    main(["-b", "7", "predict", mpath, str(fa), "--output", single])
+    main(["-b", "7", "predict", mpath, str(fa), str(odd), "--output", single])
     sharded = str(tmp_path / "sharded.tsv")
     ctx = mp.get_context("spawn")
     port = 29600 + os.getpid() % 150
-    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, str(fa), mpath, sharded)) for r in range(2)]
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, f"{fa},{odd}", mpath, sharded)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
     assert open(sharded).read() == open(single).read()
-    assert open(single).read().count("\n") > 300
+    assert open(single).read().count("\n") > 300 and "\tlast\t" in open(single).read()
+    import json
+    stats = [json.load(open(f"{sharded}.rank{r}.json")) for r in range(2)]
+    total = os.path.getsize(fa) + os.path.getsize(odd)
+    assert stats[0]["file_bytes"] == total and stats[0]["uploaded_bytes"] + stats[1]["uploaded_bytes"] == total
+    assert abs(stats[0]["uploaded_bytes"] - total / 2) < 0.15 * total                          # bytes uploaded per rank ~ file / N
+    assert stats[0]["records"] + stats[1]["records"] == 302 + 5
 
 
 
@@ -155,4 +173,15 @@ def test_bench_line_one_and_two_ranks(ranks):
     out = json.loads(lines[0])
     assert out["n_gpus"] == ranks and out["steps"] == 2 and out["value"] > 0 and out["unit"] == "Mbp/s"
     assert out["roofline"]["bound"] == "mfma" and 0 < out["roofline"]["frac"] < 1
-    assert ("cpu_baseline" in out) == (ranks == 1) and ("e2e" in out) == (ranks == 1)
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"           # at every N (rank 0, after the group is gone)
+    assert out["roofline"]["traffic_source"] is None or "STORED" in out["roofline"]["traffic_source"]
+    assert ("e2e" in out) == (ranks == 1)
+    if ranks > 1:
+        # what every rank saw: its GPU, its times -- and the sharded command line over ONE file of `ranks` records
+        assert [r["rank"] for r in out["ranks"]] == list(range(ranks)) and all(r["kernel_ms"] > 0 and r["mbp_per_s"] > 0 for r in out["ranks"])
+        assert all(r["pci_bus_id"] or r["uuid"] for r in out["ranks"]) and out["distinct_gpus"] == 1     # (both ranks on GPU 0 here)
+        sf = out["sharded_file"]
+        assert sf["records"] == ranks and sf["value"] > 0 and sf["rows_out"] > 0
+        assert sum(sf["uploaded_bytes_per_rank"]) == sf["file_bytes"]
+        assert all(abs(b - sf["file_bytes"] / ranks) < 0.1 * sf["file_bytes"] for b in sf["uploaded_bytes_per_rank"])
+        assert sf["records_per_rank"] == [1] * ranks

@@ -47,6 +47,25 @@ def trained():
     dm.close()
 
 
+def _far_windows_vs_oracle(orc, owts, model, d_idx, s, w0, nw=32, tol=1e-5):
+    """Windows [w0, w0 + nw) of a device-resident record against the float64 CPU statement (oracle/dgrp_oracle.c): the oracle is
+    handed only the bases those windows cover, so it costs milliseconds wherever in the record they lie."""
+    T = model.vecsize
+    a = w0 * s
+    tail = d_idx[a:a + (nw - 1) * s + T].cpu().numpy()
+    want = orc.nn_forward(tail, owts, s, 0, nw, np.float64)
+    got = model.forward_windows(d_idx, s, w0, nw).cpu().numpy()
+    err = float(np.abs(got - want).max())
+    assert err < tol, f"windows {w0}..{w0 + nw}: |dp| = {err:.3e} against the float64 oracle"
+    return err
+
+
+@pytest.fixture(scope="module")
+def trained_oracle_weights(orc):
+    w = synthetic.trained_weights()
+    return orc.Weights(w["kernel"], w["recurrent_kernel"], w["bias"], w["ff_kernel"], w["ff_bias"], None, 200)
+
+
 def test_20mbp_postprocessing_exact(orc, trained):
     """Scores, classes, labels and rows of a 20 Mbp record: the GPU path against the sequential
     oracle on the same merged probabilities (thousands of independently scanned stretches)."""
@@ -113,7 +132,7 @@ def test_50mbp_properties(trained):
     _size_independent_properties(trained, 50_000_000, 0, 77_776)
 
 
-def test_250mbp_properties_and_far_offsets(trained):
+def test_250mbp_properties_and_far_offsets(orc, trained, trained_oracle_weights):
     """configs[2]: the 250 Mbp chromosome the north-star target is quoted on (a 1.25 G-element merged array: the place a
     32-bit index would slip).  The property set of the 50 Mbp case, the one-call path (dgrp_predict_record, what the
     command line and bench.py run) against the staged one, and -- since no CPU statement covers this size -- windows
@@ -132,6 +151,9 @@ def test_250mbp_properties_and_far_offsets(trained):
     got = trained.forward_windows(d_idx, s, w0, nw)
     ref = trained.forward_windows_reference(d_idx, s, w0, nw)
     assert float((got - ref).abs().max()) < 1e-5
+    # ... and against the float64 oracle itself: the last 32 windows, 32 of the short last batch's, 32 from the middle
+    for start in (nwin - 32, nwin // B * B - 16, nwin // 2):
+        _far_windows_vs_oracle(orc, trained_oracle_weights, trained, d_idx, s, start)
     # placement at far offsets: full-batch windows sit at w * s, the short last batch (r windows) at
     # (nfull * r + (w - nfull * B)) * s -- for this record in the middle of the array
     nfull, r = nwin // B, nwin % B
@@ -149,7 +171,7 @@ def test_250mbp_properties_and_far_offsets(trained):
         assert bool((merged[a:a + T] >= got[w - w0]).all())
 
 
-def test_900mbp_beyond_32bit_elements(trained):
+def test_900mbp_beyond_32bit_elements(orc, trained, trained_oracle_weights):
     """A record larger than any of BASELINE's configurations: 900 Mbp (the largest chromosomes sequenced so far are of this order),
     i.e. a merged array of 4.5 G elements -- past 2^32, where an index held in 32 bits anywhere on the path would wrap -- 18 M
     windows in 18 launches, and (SURVEY 8b iii) still inside the reference's own limit of n < 2^31 for `mss_find_all`.  Checked
@@ -168,9 +190,72 @@ def test_900mbp_beyond_32bit_elements(trained):
     got = trained.forward_windows(d_idx, s, w0, nw)
     ref = trained.forward_windows_reference(d_idx, s, w0, nw)
     assert float((got - ref).abs().max()) < 1e-5
+    for start in (nwin - 32, w0 + nw - 32, (2 ** 32 // C) // s + 7):       # the last windows; the last full batch; rows around element 2^32
+        _far_windows_vs_oracle(orc, trained_oracle_weights, trained, d_idx, s, start)
     row_a, row_b = w0 * s + T, nfull * B * s
     want = torch.zeros((row_b - w0 * s + T, C), dtype=torch.float32, device=merged.device)
     for w in range(w0, nfull * B):
         a = (w - w0) * s
         want[a:a + T] = torch.maximum(want[a:a + T], got[w - w0])
     assert torch.equal(merged[row_a:row_b], want[T:T + row_b - row_a])
+
+
+def test_cfg5_contig_125mbp_u256_attention(orc):
+    """BASELINE configs[4]'s per-GPU workload in its real form: ONE 125 Mbp contig (the 3 Gbp genome is 24 of them, three per GPU)
+    through the 256-unit attention model at window 500, stride 25 -- 5 M windows, a 20 KiB/bp avg[t] spill chunked over ~150
+    launches, ~7 s of GPU time per pass.  Size-independent properties of the merged array and the rows, chunk invariance (another
+    launch size: bit-identical), the one-call path against the staged one, far-end / short-batch / middle windows against the
+    float64 oracle within 1e-5, and the merged rows under the last full-batch windows bit-identical to a max-merge done here."""
+    T, s, C, B, u = 500, 25, 5, 256, 256
+    w = orc.Weights.random(u, C, T, True, seed=21, gain=1.5)
+    w.ff_bias[0] += 1.5                          # mostly background with scattered calls (pure noise would be ~10^8 one-base rows)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    raw = synthetic.synthetic_chromosome(125_000_000, contig=9)
+    st, d_idx = upload_sequence(raw)
+    del raw
+    n = d_idx.numel()
+    nwin = len(range(0, n - T, s))
+    pipe = ContigPipeline(dm, s, B, 50, 50, True)
+    merged = pipe.merged(d_idx)
+    # chunk invariance on a 5 Mbp slice of the same record (a second full pass would double the test's 7 s for nothing new):
+    # the slice's own merged array from two launch sizes, bit for bit
+    part = d_idx[60_000_000:65_000_000]
+    m_a = ContigPipeline(dm, s, B, 50, 50, True).merged(part)
+    m_b = ContigPipeline(dm, s, B, 50, 50, True, chunk_windows=10_000).merged(part)
+    assert torch.equal(m_a, m_b)
+    del m_a, m_b
+    nfull, r = nwin // B, nwin % B
+    covered = (nfull * B - 1) * s + T
+    assert float(merged[:covered].max(dim=1).values.min()) >= 1.0 / C - 1e-6
+    assert float(merged[:covered].sum(dim=1).min()) >= 1.0 - 1e-5
+    assert float(merged.max()) <= 1.0 + 1e-6 and float(merged.min()) >= 0.0
+    last_placed = max((nfull * r + r - 1) * s + T if r else 0, covered)
+    assert float(merged[last_placed:].abs().max()) == 0.0
+    labels = pipe.labels(merged)
+    rows = pipe.segments(labels, st)
+    assert (rows["start"] < rows["end"]).all() and (rows["start"][1:] >= rows["end"][:-1]).all()
+    assert rows["start"].min() >= st and rows["end"].max() <= st + n and (rows["label"] > 0).all()
+    lab = labels.cpu().numpy()
+    sc, cl = orc.scores(merged[-2_000_000:].cpu().numpy())          # the score transform at the far end, bit for bit
+    sc_d = torch.empty(2_000_000, dtype=torch.float64, device=merged.device)
+    cl_d = torch.empty(2_000_000, dtype=torch.int8, device=merged.device)
+    from deepgrp_amd._lib import check, lib
+    from deepgrp_amd.pipeline import stream_ptr
+    tail = merged[-2_000_000:].contiguous()
+    check(lib().dgrp_scores(tail.data_ptr(), 2_000_000, C, sc_d.data_ptr(), cl_d.data_ptr(), stream_ptr()), "dgrp_scores")
+    assert np.array_equal(sc_d.cpu().numpy().view(np.int64), sc.view(np.int64)) and np.array_equal(cl_d.cpu().numpy(), cl)
+    np.testing.assert_array_equal(_rows3(rows), orc.segments(lab, st))
+    one_call = pipe.run_idx(d_idx, st)
+    np.testing.assert_array_equal(_rows3(one_call), _rows3(rows))
+    for start in (nwin - 32, nfull * B - 16, nwin // 2, 0):
+        _far_windows_vs_oracle(orc, w, dm, d_idx, s, start)
+    # merged rows under the last full-batch windows that no other window reaches
+    nw = 512
+    w0 = nfull * B - nw
+    got = dm.forward_windows(d_idx, s, w0, nw)
+    row_a, row_b = w0 * s + T, nfull * B * s
+    want = torch.zeros((row_b - w0 * s + T, C), dtype=torch.float32, device=merged.device)
+    for k in range(nw):
+        want[k * s:k * s + T] = torch.maximum(want[k * s:k * s + T], got[k])
+    assert torch.equal(merged[row_a:row_b], want[T:T + row_b - row_a])
+    dm.close()

@@ -631,6 +631,7 @@ def test_split_plan_partitions_rows_and_covers_spills():
                 nwin, first_short, shares, owned, short = split_plan(n, T, s, B, world)
                 assert nwin == len(range(0, n - T, s)) and first_short == nwin // B * B
                 assert owned[0][0] == 0 and owned[-1][1] == n and all(owned[k][1] == owned[k + 1][0] for k in range(world - 1))
+                assert all(0 <= lo <= hi <= n for lo, hi in owned)                  # (step > T once gave a rank a negative range)
                 assert shares[0][0] == 0 and shares[-1][1] == first_short and all(shares[k][1] == shares[k + 1][0] for k in range(world - 1))
                 for k, (a, b) in enumerate(shares):
                     for w in (a, b - 1) if b > a else ():
@@ -644,6 +645,157 @@ def test_split_plan_partitions_rows_and_covers_spills():
                     assert short == (nfull * r * s, min((nfull * r + r - 1) * s + T, n))
                 else:
                     assert short == (0, 0)
+
+
+def test_split_plan_step_larger_than_window():
+    """split_plan(700, 30, 300, 3, 2) returned owned = [(0, 900), (900, 700)]."""
+    from deepgrp_amd.distributed import split_plan
+    for n, T, s, B, world in ((700, 30, 300, 3, 2), (700, 30, 300, 3, 8), (100, 10, 95, 1, 3), (31, 30, 300, 3, 4)):
+        _nwin, _fs, _shares, owned, _short = split_plan(n, T, s, B, world)
+        assert owned[0][0] == 0 and owned[-1][1] == n
+        assert all(0 <= lo <= hi <= n for lo, hi in owned) and all(owned[k][1] == owned[k + 1][0] for k in range(world - 1))
+
+
+# ---- rank-local ingest of the sharded command line (deepgrp_amd/__main__.py::_predict_sharded)
+def _write_many(path, lengths, rng, width=70):
+    with open(path, "wb") as fh:
+        for k, n in enumerate(lengths):
+            seq = bytes(rng.choice(list(b"ACGTN"), size=n).astype(np.uint8))
+            fh.write(b">r%d some text\n" % k + b"\n".join(seq[i:i + width] for i in range(0, len(seq), width)) + b"\n")
+
+
+def test_chunk_starts_host_slices_concatenate(tmp_path):
+    from deepgrp_amd.fasta import chunk_starts_host
+    rng = np.random.default_rng(3)
+    path = tmp_path / "m.fa"
+    _write_many(path, [int(x) for x in rng.integers(0, 400, size=60)], rng)
+    raw = path.read_bytes()
+    want = [0] + [i + 1 for i in range(len(raw) - 1) if raw[i:i + 2] == b"\n>"]
+    assert chunk_starts_host(str(path)).tolist() == want
+    for world in (2, 3, 7, 64):
+        got = np.concatenate([chunk_starts_host(str(path), r * len(raw) // world, (r + 1) * len(raw) // world) for r in range(world)])
+        assert got.tolist() == want
+    # slice edges ON a chunk start and directly behind one
+    for cut in (want[5], want[5] + 1, want[9] - 1):
+        got = np.concatenate([chunk_starts_host(str(path), 0, cut), chunk_starts_host(str(path), cut, len(raw))])
+        assert got.tolist() == want
+    empty = tmp_path / "e.fa"
+    empty.write_bytes(b"")
+    assert chunk_starts_host(str(empty)).size == 0
+    nohead = tmp_path / "n.fa"
+    nohead.write_bytes(b"ACGT\n>a\nAC\n")
+    assert chunk_starts_host(str(nohead)).tolist() == [0, 5]
+
+
+def test_plan_file_shares_partitions_the_bytes():
+    from deepgrp_amd.distributed import plan_file_shares
+    rng = np.random.default_rng(5)
+    # (1) BASELINE configs[3]: 8 equal contigs on 8 ranks -> one each; (2) thousands of short records -> a few ranges per rank;
+    # (3) mixed, two files and host-parsed extras; (4) fewer chunks than ranks
+    cases = [([np.arange(8) * 1000], [8000], [], 8), ([np.arange(5000) * 100], [500000], [], 8),
+             ([np.sort(rng.choice(10 ** 6, 300, replace=False)) * 1, np.array([0, 10, 5000])], [10 ** 6 + 7, 9000], [3000, 10, 70000], 3),
+             ([np.array([0, 400])], [1000], [], 8), ([np.zeros(0, np.int64)], [0], [], 2)]
+    for tables, sizes, extra, world in cases:
+        tables = [np.concatenate([[0], t[t > 0]]).astype(np.int64) if s else t for t, s in zip(tables, sizes)]
+        ranges, extras = plan_file_shares(tables, sizes, extra, world)
+        assert len(ranges) == world and len(extras) == world
+        assert sorted(i for e in extras for i in e) == list(range(len(extra)))
+        for f, (t, size) in enumerate(zip(tables, sizes)):
+            got = sorted((a, b) for r in ranges for ff, a, b in r if ff == f)
+            assert all(a < b for a, b in got)
+            assert [a for a, _b in got][:1] == ([0] if size else []) and all(x[1] == y[0] for x, y in zip(got, got[1:]))
+            assert (got[-1][1] if got else 0) == size
+            assert all(a in set(t.tolist()) for a, _b in got)                      # every range starts at a chunk start
+        loads = [sum(b - a for _f, a, b in r) + sum(extra[i] for i in e) for r, e in zip(ranges, extras)]
+        total = sum(sizes) + sum(extra)
+        biggest = max([int(x) for t, s in zip(tables, sizes) for x in np.diff(np.concatenate([t, [s]]))] + list(extra) + [0])
+        assert max(loads) <= total / world + max(biggest, total / (world * 8)) + 1
+    ranges, _ = plan_file_shares([np.arange(8) * 1000], [8000], [], 8)
+    assert all(len(r) == 1 and r[0][2] - r[0][1] == 1000 for r in ranges)
+    ranges, _ = plan_file_shares([np.arange(5000) * 100], [500000], [], 8)
+    assert max(len(r) for r in ranges) <= 8                                        # contiguous runs, not 625 scattered records
+
+
+def _sharded_cli_worker(rank, world, port, fa1, fa2, out, q):
+    """_predict_sharded with the device pieces replaced by host stand-ins: the planning, the order keys and the collectives are real."""
+    import argparse
+
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo")
+    from deepgrp_amd import fasta
+    from deepgrp_amd.__main__ import CommandLineParser
+    from deepgrp_amd.pipeline import SEGMENT_DTYPE
+    torch.cuda.current_device = lambda: 0                                      # gather_records only builds a device object from it
+    read = []
+
+    def host_ingest(path, ranges=None, *a, **k):
+        raw = open(path, "rb").read()
+        for lo, hi in ranges:
+            read.append(hi - lo)
+            fasta.UPLOAD_STATS["bytes"] += hi - lo
+            starts = [lo] + [i + 1 for i in range(lo, hi - 1) if raw[i:i + 2] == b"\n>"] + [hi]
+            for a_, b_ in zip(starts[:-1], starts[1:]):
+                loop = fasta.LineLoop()
+                for h, s in loop.feed(fasta._text_lines(raw[a_:b_]), tag=a_):
+                    yield loop.last_key, h, s
+                for h, s in loop.flush():
+                    yield loop.last_key, h, s
+    fasta.ingest_ranges = host_ingest
+
+    class Runner:                                                               # rows = f(record): two rows per non-empty record
+        def results(self, records):
+            for key, seq in records:
+                rows = np.zeros(2 if len(seq) else 0, SEGMENT_DTYPE)
+                for j in range(len(rows)):
+                    rows[j] = (j * 5, j * 5 + len(seq), 1 + seq.count("A") % 3, 0)
+                yield "one", key, rows
+
+    def records_of(name):                                                      # the host-parsed kind of input (stdin / npz)
+        yield from [("x1", "ACGTA" * 7), ("x2", ""), ("x3", "AAA")]
+
+    args = argparse.Namespace(FASTA=[fa1, "-", fa2])
+    stream = open(out, "w") if rank == 0 else None
+    CommandLineParser._predict_sharded(args, Runner(), records_of, stream)
+    if stream:
+        stream.close()
+    q.put((rank, sum(read), CommandLineParser.last_sharded))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_cli_gloo_world2(tmp_path):
+    """The N > 1 command line on CPU (gloo, world_size 2): rank-local byte ranges (each rank reads about half of the files'
+    bytes, together all of them once), rows gathered to rank 0 and written in input order -- three inputs, the middle one of
+    the host-parsed kind."""
+    import torch.multiprocessing as mp
+    from deepgrp_amd.fasta import read_multi_fasta_file
+    rng = np.random.default_rng(11)
+    fa1, fa2, out = tmp_path / "a.fa", tmp_path / "b.fa", tmp_path / "out.tsv"
+    _write_many(fa1, [int(x) for x in rng.integers(0, 3000, size=120)] + [60_000, 5, 45_000], rng)
+    _write_many(fa2, [20_000, 20_000, 30], rng)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sharded_cli_worker, args=(r, 2, port, str(fa1), str(fa2), str(out), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (n, st) for r, n, st in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = os.path.getsize(fa1) + os.path.getsize(fa2)
+    assert got[0][0] + got[1][0] == total and abs(got[0][0] - got[1][0]) < 0.2 * total
+    assert got[0][1]["uploaded_bytes"] == got[0][0] and got[0][1]["file_bytes"] == total
+    want = []
+    for name, recs in ((str(fa1), read_multi_fasta_file(str(fa1))), ("-", [("x1", "ACGTA" * 7), ("x2", ""), ("x3", "AAA")]),
+                       (str(fa2), read_multi_fasta_file(str(fa2)))):
+        for h, s in recs:
+            s = s.decode() if isinstance(s, bytes) else s
+            for j in range(2 if len(s) else 0):
+                want.append(f"{name}\t{h}\t{j * 5}\t{j * 5 + len(s)}\t{1 + s.count('A') % 3}\n")
+    assert open(out).read() == "".join(want)
 
 
 def _raise_worker(rank, world, port, q):
