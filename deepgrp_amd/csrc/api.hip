@@ -226,6 +226,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     m->nfrag = 3 * (m->KS + 1) + 3;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
     m->d_pack_lo = nullptr; m->precision = 0; m->d_pack16 = nullptr; m->d_xtab = nullptr; m->d_stream = nullptr;
+    m->d_packw = nullptr; m->d_xtabw = nullptr; m->NU16 = 0;
     const int KS = m->KS, NF = m->nfrag, u3 = 3 * u;
     // The update z*h + (1-z)*tanh(g) can be written with ONE reciprocal, of (1 + 2^az)(1 + 2^ag), if that
     // product cannot overflow: |h| <= 1 and 0 < r < 1 bound both pre-activations by the weights' absolute
@@ -377,6 +378,54 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
             CREATE_HIP(hipMalloc((void **)&m->d_xtab, xt.size() * 4));
             CREATE_HIP(hipMemcpy(m->d_xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice));
         }
+        if (u <= 64) {
+            // gru_wave_kernel's operands (gru_wave.hip): every wave holds ALL units.  A fragment of v_mfma_f32_16x16x32_f16: lane l, element j
+            // <-> A[row l & 15][k 8 (l >> 4) + j]; here row = unit 16 ug + (l & 15), k = recurrent row 32 ks + 8 (l >> 4) + j.  Dense B fragment:
+            // lane l, element j <-> B[k 8 (l >> 4) + j][column l & 15] = 0.5 * FF kernel[row0 + 32 ks + k][class].  Same scaled values and
+            // hi/lo split as the other split-operand kernels.
+            const int NU = (u + 15) / 16, KSw = (NU + 1) / 2, UP16 = 16 * NU, NFw = 6 * KSw * NU;
+            static const int orderw[3] = { 1, 2, 0 };                                   // r, g, z in Keras column blocks [z | r | h]
+            std::vector<uint16_t> pw((size_t)(NFw + 2 * KSw) * 64 * 8, 0);
+            for (int gi = 0; gi < 3; ++gi)
+                for (int ks = 0; ks < KSw; ++ks)
+                    for (int ug = 0; ug < NU; ++ug)
+                        for (int l = 0; l < 64; ++l)
+                            for (int j = 0; j < 8; ++j) {
+                                const int g = orderw[gi], unit = 16 * ug + (l & 15), k = 32 * ks + 8 * (l >> 4) + j;
+                                if (unit >= u || k >= u) continue;
+                                const float gs = g < 2 ? -1.4426950408889634f : 2.8853900817779268f;
+                                const float x = gs * rec[(size_t)k * u3 + g * u + unit];
+                                const uint16_t hi = f2h(x);
+                                pw[((size_t)((gi * KSw + ks) * NU + ug) * 64 + l) * 8 + j] = hi;
+                                pw[((size_t)(((3 + gi) * KSw + ks) * NU + ug) * 64 + l) * 8 + j] = f2h(x - h2f(hi));
+                            }
+            const int drow0 = attention ? u : 0;
+            for (int ks = 0; ks < KSw; ++ks)
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int k = 32 * ks + 8 * (l >> 4) + j, c = l & 15;
+                        if (k >= u || c >= C) continue;
+                        const float v = 0.5f * ffk[(size_t)(drow0 + k) * C + c];
+                        const uint16_t hi = f2h(v);
+                        pw[((size_t)(NFw + 2 * ks) * 64 + l) * 8 + j] = hi;
+                        pw[((size_t)(NFw + 2 * ks + 1) * 64 + l) * 8 + j] = f2h(v - h2f(hi));
+                    }
+            std::vector<float> xt((size_t)5 * 4 * UP16, 0.0f);
+            const double cs = -1.4426950408889634, ch = 2.8853900817779268;
+            for (int b = 0; b < 5; ++b)
+                for (int unit = 0; unit < u; ++unit) {
+                    float *row = &xt[(size_t)b * 4 * UP16];
+                    row[0 * UP16 + unit] = (float)(cs * ((double)kernel[(size_t)b * u3 + u + unit] + (double)bias[u + unit] + (double)bias[u3 + u + unit]));
+                    row[1 * UP16 + unit] = (float)(ch * (double)bias[u3 + 2 * u + unit]);
+                    row[2 * UP16 + unit] = (float)(cs * ((double)kernel[(size_t)b * u3 + unit] + (double)bias[unit] + (double)bias[u3 + unit]) + (m->onercp ? 1.0 : 0.0));
+                    row[3 * UP16 + unit] = (float)(ch * ((double)kernel[(size_t)b * u3 + 2 * u + unit] + (double)bias[2 * u + unit]));
+                }
+            CREATE_HIP(hipMalloc((void **)&m->d_packw, pw.size() * 2));
+            CREATE_HIP(hipMemcpy(m->d_packw, pw.data(), pw.size() * 2, hipMemcpyHostToDevice));
+            CREATE_HIP(hipMalloc((void **)&m->d_xtabw, xt.size() * 4));
+            CREATE_HIP(hipMemcpy(m->d_xtabw, xt.data(), xt.size() * 4, hipMemcpyHostToDevice));
+            m->NU16 = NU;
+        }
         // Default for the models it covers: the split-operand kernel, the one that keeps every base within the 1e-3 of
         // the north star whatever the model's conditioning.  dgrp_model_set_precision(m, 0) or
         // DGRP_GRU_PRECISION=0 selects the 2.5x faster fp16-operand kernel.
@@ -415,6 +464,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     m->nfrag = 4 * (m->KS + 1) + 2;
     m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
     m->d_pack_lo = nullptr; m->precision = 0; m->d_pack16 = nullptr; m->d_xtab = nullptr; m->d_stream = nullptr;
+    m->d_packw = nullptr; m->d_xtabw = nullptr; m->NU16 = 0;
     const int KS = m->KS, NF = m->nfrag, u4 = 4 * u;
     std::vector<uint16_t> pack((size_t)m->NW * NF * 64 * 8, 0);
     frag_writer fw{ pack, NF };
@@ -468,6 +518,8 @@ DGRP_EXPORT int dgrp_model_destroy(dgrp_model *m)
     if (m->d_pack16) (void)hipFree(m->d_pack16);
     if (m->d_xtab) (void)hipFree(m->d_xtab);
     if (m->d_stream) (void)hipFree(m->d_stream);
+    if (m->d_packw) (void)hipFree(m->d_packw);
+    if (m->d_xtabw) (void)hipFree(m->d_xtabw);
     delete m;
     return DGRP_OK;
 }

@@ -22,6 +22,12 @@ struct dgrp_model {
     // GRU with 129-256 units and LSTM, for rnn_split_stream_kernel (rnn_stream.hip): the recurrent kernel as 32x32x16 fragments, hi and
     // lo halves, in consumption order [NW][KS][2 G][64] (k-step major; G hi fragments in pack gate order, then the G lo fragments), or NULL
     uint4 *d_stream;
+    // GRU up to 64 units, for gru_wave_kernel (gru_wave.hip): NU16 = ceil(u / 16) unit groups, KS = ceil(NU16 / 2) k-steps of 32; the recurrent
+    // kernel as 16x16x32 A fragments [((pass * 3 + gate) * KS + k-step) * NU16 + unit group][64] (pass hi|lo, gates r, g, z), then the Dense
+    // kernel as B fragments [k-step][hi|lo][64]; the input projection as a table [5 bases][4 kinds][16 NU16 units] fp32, exp2 domain
+    uint4 *d_packw;
+    float *d_xtabw;
+    int NU16;
     float *d_ffb;     // [16] dense bias, zero padded
     float *d_scale;   // [UP] attention scale (zero padded) or NULL
     float *d_wtop;    // [UP][16] rows of the dense kernel that multiply the context vector, or NULL
@@ -49,6 +55,10 @@ int dgrp_attention_launch(const dgrp_model *m, int64_t s, dgrp_placement place, 
 // rnn_stream.hip: the streamed split-operand kernel (cell 0 = GRU with 5..8 waves, 1 = LSTM with 1..4 waves)
 struct gru_params;
 int dgrp_stream_launch(const gru_params &p, int cell, int NW, int64_t groups, size_t lds, hipStream_t stream);
+// gru_wave.hip: the wave-local split-operand kernel of GRU models up to 64 units (groups = groups of 16 windows, one per wave)
+int dgrp_wave_carve(int NU, gru_params &p, int mode, int64_t s, int64_t budget);
+int dgrp_wave_table_bytes(int NU);
+int dgrp_wave_launch(const gru_params &p, int NU, int64_t groups, int wave_bytes, bool onercp, hipStream_t stream);
 // batched records (mode 0): see gru_kernel.hip
 int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, const void *d_recs, const int64_t *d_wg_first,
                           int64_t nrec, int64_t total_groups, int mode, float *d_out, void *d_avg, hipStream_t stream);

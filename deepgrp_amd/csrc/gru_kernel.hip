@@ -1201,6 +1201,15 @@ static int64_t tile_budget(const dgrp_model *m, bool split)
 #define DGRP_SPLIT2_PAD 16
 #define DGRP_SPLIT2_XTAB_BYTES (5 * (4 * 128 * 4 + 32))
 static bool split2_applies(const dgrp_model *m) { return m->NW == 4 && m->d_pack16 && !getenv("DGRP_SPLIT_ONE_TILE"); }
+// gru_wave_kernel (gru_wave.hip): GRU up to 64 units; four waves' carves and the table must fit the CU's LDS -- a property of the model's
+// window and step, never of the record
+static bool wave_applies(const dgrp_model *m) { return m->cell == 0 && m->NU16 > 0 && m->d_packw && !getenv("DGRP_SPLIT_ONE_TILE"); }
+static int wave_try(const dgrp_model *m, gru_params &p, int mode, int64_t s)
+{
+    const int64_t budget = (160 * 1024 - dgrp_wave_table_bytes(m->NU16)) / 4 / 16 * 16;
+    const int wb = dgrp_wave_carve(m->NU16, p, mode, s, budget);
+    return wb <= budget ? wb : 0;
+}
 
 int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place,
                     int64_t w0, int64_t nw, int mode, float *d_out, void *d_avg, hipStream_t stream)
@@ -1228,8 +1237,12 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     const bool split = use_split(m, mode);
     p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
     p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0; p.stream = m->d_stream;
+    p.packw = m->d_packw; p.xtabw = m->d_xtabw; p.avg_up = m->UP;
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
+    if (split && wave_applies(m)) {
+        if (const int wb = wave_try(m, p, mode, s)) return dgrp_wave_launch(p, m->NU16, groups, wb, m->onercp != 0, stream);
+    }
     if (split && split2_applies(m)) {
         // 128-unit class: two row tiles per workgroup, everything resident, whenever two carves and the table fit the CU's LDS
         // (a property of the model's window size, not of the record: a record never changes kernels with the way it is batched)
@@ -1307,7 +1320,11 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     const bool split = use_split(m, mode);
     p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
     p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0; p.stream = m->d_stream;
+    p.packw = m->d_packw; p.xtabw = m->d_xtabw; p.avg_up = m->UP;
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
+    if (split && wave_applies(m)) {
+        if (const int wb = wave_try(m, p, mode, s)) return dgrp_wave_launch(p, m->NU16, total_groups, wb, m->onercp != 0, stream);
+    }
     if (split && split2_applies(m)) {
         const int half_bytes = (int)dgrp_align_up((int64_t)gru_tile_carve(m, p, mode, s, true, DGRP_SPLIT2_PAD, 74 * 1024), 256);
         if (2 * half_bytes + DGRP_SPLIT2_XTAB_BYTES <= 160 * 1024) {

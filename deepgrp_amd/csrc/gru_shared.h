@@ -48,6 +48,11 @@ struct gru_params {
     int xtab_off;
     // rnn_split_stream_kernel only (rnn_stream.hip): hi and lo recurrent fragments in consumption order, [NW][KS][2 G][64]
     const uint4 *stream;
+    // gru_wave_kernel only (gru_wave.hip, GRU up to 64 units): all-unit 16x16x32 A fragments + Dense B fragments, the input-projection
+    // table [5][4][16 NU], and the row length (floats) of the avg[t] spill (the model's UP)
+    const uint4 *packw;
+    const float *xtabw;
+    int avg_up;
 };
 
 // The packed gate weights carry the exp2 scale (-log2 e for z and r, 2 log2 e for the candidate),
@@ -370,6 +375,16 @@ __device__ __forceinline__ void split_hi_lo4(const float h[4], uint2 &hv, uint2 
     hv = split_pack4(r);
     split_residual4(r, hv);
     lv = split_pack4(r);
+}
+
+// attention pre-pass of gru_wave_kernel: (h + h of the other strand) / 2, the other strand's row sitting 8 lanes away in the same DPP
+// row of 16 -- one rounding (halving is exact), the value of rounding the sum and halving it
+__device__ __forceinline__ float wave_half_sum(float h)
+{
+#pragma clang fp contract(off)
+    const float other = row_ror<8>(h);
+    const float half = 0.5f * h;
+    return __builtin_fmaf(0.5f, other, half);
 }
 
 // LSTM cell update of one (row, unit) for the split-operand kernel, every a*b+c an explicit fma and nothing left to contract, so

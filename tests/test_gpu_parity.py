@@ -124,6 +124,12 @@ FORWARD_CASES = [
     (60, 342, True, 1.0, 50, 20), (64, 30, False, 2.0, 4, 50), (32, 50, True, 1.0, 5, 17),
     (96, 25, False, 1.0, 3, 35), (8, 20, True, 1.0, 2, 19), (100, 64, False, 1.5, 16, 16),
     (256, 60, False, 1.0, 25, 40), (256, 500, True, 1.5, 25, 19), (160, 40, True, 1.0, 9, 33), (200, 30, False, 2.0, 5, 17),
+    # the reference's own model sizes (gru_units ~ qnormal(34, 5, 2), vecsize ~ qnormal(200, 20, 2), attention; notebooks/DeepGRP.ipynb:
+    # 153-154) on gru_wave_kernel: every count of 16-unit groups, with and without attention, ragged window counts (the wave's two
+    # row tiles of 8 windows: 1, 7, 8, 9, 15, 17 windows leave a tile empty, partly filled or the whole second group idle)
+    (34, 200, True, 1.0, 50, 23), (36, 210, True, 2.0, 50, 40), (40, 180, False, 1.5, 50, 17), (44, 200, True, 1.0, 50, 9),
+    (48, 64, False, 2.0, 8, 65), (16, 33, True, 1.5, 4, 15), (20, 40, False, 1.0, 5, 7), (50, 90, True, 3.0, 10, 1),
+    (33, 25, False, 1.0, 3, 8), (64, 120, True, 2.5, 20, 129), (12, 20, False, 1.0, 2, 31), (60, 342, False, 1.0, 50, 33),
 ]
 
 
@@ -235,7 +241,13 @@ def test_predict_on_batch_keras_style(dev, orc):
                                                   (5000, 200, 50, 7, 128, False), (5000, 200, 50, 256, 128, False),
                                                   (777, 30, 4, 10, 32, True), (200, 200, 50, 4, 32, False),
                                                   (201, 200, 50, 4, 32, False), (3000, 100, 300, 3, 32, False),
-                                                  (3000, 500, 25, 256, 256, True)])
+                                                  (3000, 500, 25, 256, 256, True),
+                                                  # the row kernel's four-window workgroups across the partial-last-batch boundary
+                                                  # (nwin % 4 != 0, nfull * B % 4 != 0: an idle fourth wave, the image's flush guard)
+                                                  (1500, 100, 10, 7, 128, True), (1507, 100, 10, 5, 160, True), (1203, 90, 10, 9, 72, True),
+                                                  # gru_wave_kernel: 16-window groups of two 8-window tiles, every image / no-image path
+                                                  (2000, 200, 50, 7, 36, False), (2013, 200, 50, 5, 44, True), (1000, 60, 3, 11, 60, True),
+                                                  (9000, 342, 50, 256, 60, True), (9000, 342, 50, 13, 48, False), (1700, 1500, 50, 3, 20, False)])
 def test_forward_merge_placement_exact(dev, orc, L, N, T, s, B, u, attention):
     """The fused max-merge must equal get_max applied batch by batch to the SAME probabilities
     (bit for bit), incl. the partial-last-batch offset, and be within 1e-3 of the

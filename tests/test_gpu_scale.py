@@ -51,6 +51,7 @@ def _far_windows_vs_oracle(orc, owts, model, d_idx, s, w0, nw=32, tol=1e-5):
     """Windows [w0, w0 + nw) of a device-resident record against the float64 CPU statement (oracle/dgrp_oracle.c): the oracle is
     handed only the bases those windows cover, so it costs milliseconds wherever in the record they lie."""
     T = model.vecsize
+    w0 = max(0, min(w0, len(range(0, d_idx.numel() - T, s)) - nw))        # (a short last batch may hold fewer than nw / 2 windows)
     a = w0 * s
     tail = d_idx[a:a + (nw - 1) * s + T].cpu().numpy()
     want = orc.nn_forward(tail, owts, s, 0, nw, np.float64)
