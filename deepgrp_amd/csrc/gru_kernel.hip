@@ -44,6 +44,7 @@
 //   attention_wave_kernel<UP,CM> (up to 64 units) / attention_row_kernel<AT,EPL,TT> (65-256 units)   second pass of attention models (after a MODE 2 pre-pass)
 // MODE 0: forward + max-merge into [n, C]; 1: probabilities [nw, T, C]; 2: attention pre-pass (avg[t] spill + partial logits)
 #include "gru_shared.h"
+#include <mutex>
 template <int NW, int MODE, bool ONERCP>
 __global__ void __launch_bounds__(64 * NW, 2) gru_fused_kernel(const gru_params pin)
 {
@@ -885,12 +886,15 @@ __device__ __forceinline__ float att_elem(const att_chunk (&row)[N], int k)
     else return __builtin_bit_cast(f32x4, row[k / 4])[k % 4];
 }
 
+#ifndef DGRP_ATT_OCC
+#define DGRP_ATT_OCC 1
+#endif
 template <int UP, int CM, typename AT>
-__global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? 1 : 2) attention_wave_kernel(const att_params p)
+__global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? DGRP_ATT_OCC : 2) attention_wave_kernel(const att_params p)
 {
     constexpr int CT = UP <= 64 ? 64 : 128;                  // context registers per lane (butterfly width)
     constexpr int EPC = 16 / sizeof(AT);                     // elements per 16-byte chunk
-    __shared__ __attribute__((aligned(16))) float qs[4][UP][2];   // per wave: {c*q[k], -2*scale[k]}
+    __shared__ __attribute__((aligned(16))) float qs[4][UP / 2][4];   // per wave and unit pair: {c q[k], c q[k+1], -2 scale[k], -2 scale[k+1]}
     __shared__ __attribute__((aligned(16))) AT tile[4][64][UP + EPC];
     extern __shared__ __attribute__((aligned(16))) unsigned char att_dyn[];
     unsigned *obuf = reinterpret_cast<unsigned *>(att_dyn);  // merge: max image of the rows the 16 windows cover
@@ -907,69 +911,120 @@ __global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? 1 : 2) at
         __syncthreads();
     }
     constexpr float C2 = 2.8853900817779268f;                // 2 log2 e
+    // a tile of 64 steps is fetched with fully coalesced 16-byte loads (1 KiB per wave instruction; a lane reading
+    // its own 2*UP-byte row would touch 64 cache lines per instruction and thrash the 16 KiB L1), ahead of its use,
+    // and turned into row-per-lane through the wave's private LDS tile (pitch UP + 8 halves: conflict-free both ways)
+    constexpr int CPR = UP / EPC, TP = UP + EPC;             // 16-byte chunks per row, LDS row pitch
+    AT *mytile = &tile[wave][0][0];
+    // Tiles in flight per wave, in registers: with the 512-register budget of a lone wave a second tile ahead is free.
+    constexpr int DEPTH = (sizeof(AT) == 4 && UP <= 64 && DGRP_ATT_OCC == 1) ? 2 : 1;
+    constexpr bool AHEAD = UP * sizeof(AT) <= 128 || UP <= 64;   // beyond 64 units the registers for a tile in flight are gone
+    constexpr int QN = (UP + 63) / 64;                       // units per lane of a window's q row (k = lane, lane + 64)
+    constexpr bool PIPE = sizeof(AT) == 4 && UP <= 64 && DGRP_ATT_OCC == 1;   // a lone wave per SIMD: registers to spare for the next window's first loads
+    constexpr int PCH = (CM <= 8 && PIPE) ? 8 : 0;           // 64-step chunks of stored logit halves kept in registers (T <= 512)
+    att_chunk nxt[DEPTH][CPR];
+    auto fetch = [&](att_chunk (&dst)[CPR], const AT *avg, int t0) {
+#pragma unroll
+        for (int j = 0; j < CPR; ++j) {
+            // steps behind the window's end read its last row again (their weight below is 0): a predicated load sits in a basic
+            // block of its own, and behind 16 such blocks the compiler's counter analysis falls back to s_waitcnt vmcnt(0) in front of
+            // the LDS writes -- every tile in flight drained, the second tile ahead worth nothing
+            const int c = j * 64 + lane, r = c / CPR;
+            const int rr = min(t0 + r, T - 1);
+            dst[j] = *reinterpret_cast<const att_chunk *>(avg + (int64_t)rr * UP + (c % CPR) * EPC);
+        }
+    };
+    // what does not change from window to window: the scale and its sum, this lane's rows of W_top
+    float sc2[QN], ssum = 0.0f, wt[QN][CM];
+#pragma unroll
+    for (int i = 0; i < QN; ++i) {
+        const int k = lane + 64 * i;
+        const float sc = k < UP ? p.scale[k] : 0.0f;
+        sc2[i] = -2.0f * sc;
+        ssum += sc;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) wt[i][c] = (k < UP && c < C) ? p.wtop[k * 16 + c] : 0.0f;
+    }
+    ssum = wave_allsum(ssum);
+    // A window's first loads -- its q row (the Average of the two final states = avg[T-1]) and its first tiles -- are requested while
+    // the window before it is still in its butterfly and output phase: a wave walks four windows, and with every window starting cold
+    // (q row, then the first tiles, then the stored logit halves chunk by chunk: ~7 of a window's 24 us) the kernel sat in s_waitcnt
+    // 40 % of its time (SQ_WAIT_ANY) at 3.8 TB/s.
+    AT qn[QN];
+    auto start_window = [&](int64_t wl) {
+        const AT *avg = reinterpret_cast<const AT *>(p.avg) + wl * (int64_t)T * UP;
+#pragma unroll
+        for (int i = 0; i < QN; ++i) qn[i] = avg[(int64_t)(T - 1) * UP + min(lane + 64 * i, UP - 1)];
+        if (AHEAD) {
+            fetch(nxt[0], avg, 0);
+            if constexpr (DEPTH == 2) fetch(nxt[1], avg, 64);
+        }
+    };
+    if (PIPE && wave < nvalid) start_window(wg0 + wave);
   for (int wi = wave; wi < nvalid; wi += 4) {
     const int64_t wl = wg0 + wi;
     const AT *avg = reinterpret_cast<const AT *>(p.avg) + wl * (int64_t)T * UP;
-    float ssum = 0.0f;
-    for (int k = lane; k < UP; k += 64) {
-        const float sc = p.scale[k];
-        qs[wave][k][0] = C2 * (float)avg[(int64_t)(T - 1) * UP + k];      // Average of the two final states = avg[T-1]
-        qs[wave][k][1] = -2.0f * sc;
-        ssum += sc;
+    if (!PIPE) start_window(wl);
+#pragma unroll
+    for (int i = 0; i < QN; ++i) {
+        const int k = lane + 64 * i;
+        if (k < UP) {
+            qs[wave][k >> 1][k & 1] = C2 * (float)qn[i];
+            qs[wave][k >> 1][2 + (k & 1)] = sc2[i];
+        }
     }
-    ssum = wave_allsum(ssum);
     float ctx[CT];
 #pragma unroll
     for (int k = 0; k < CT; ++k) ctx[k] = 0.0f;
     float run_m = -INFINITY, run_l = 0.0f;
-    // a tile of 64 steps is fetched with fully coalesced 16-byte loads (1 KiB per wave instruction; a lane reading
-    // its own 2*UP-byte row would touch 64 cache lines per instruction and thrash the 16 KiB L1), one tile ahead,
-    // and turned into row-per-lane through the wave's private LDS tile (pitch UP + 8 halves: conflict-free both ways)
-    constexpr int CPR = UP / EPC, TP = UP + EPC;             // 16-byte chunks per row, LDS row pitch
-    AT *mytile = &tile[wave][0][0];
-    att_chunk nxt[CPR];
-    auto fetch = [&](int t0) {
+    for (int tb = 0; tb < T; tb += 64 * DEPTH) {
 #pragma unroll
-        for (int j = 0; j < CPR; ++j) {
-            const int c = j * 64 + lane, r = c / CPR;
-            nxt[j] = t0 + r < T ? *reinterpret_cast<const att_chunk *>(avg + (int64_t)t0 * UP + (int64_t)c * EPC) : att_chunk{ 0u, 0u, 0u, 0u };
-        }
-    };
-    constexpr bool AHEAD = UP * sizeof(AT) <= 128 || UP <= 64;   // beyond 64 units the registers for a tile in flight are gone
-    if (AHEAD) fetch(0);
-    for (int t0 = 0; t0 < T; t0 += 64) {
+      for (int d = 0; d < DEPTH; ++d) {
+        const int t0 = tb + 64 * d;
+        if (t0 >= T) break;
         const int t = t0 + lane;
         const bool ok = t < T;
-        if (!AHEAD) fetch(t0);
+        if (!AHEAD) fetch(nxt[d], avg, t0);
 #pragma unroll
         for (int j = 0; j < CPR; ++j) {
             const int c = j * 64 + lane;
-            *reinterpret_cast<att_chunk *>(mytile + (c / CPR) * TP + (c % CPR) * EPC) = nxt[j];
+            *reinterpret_cast<att_chunk *>(mytile + (c / CPR) * TP + (c % CPR) * EPC) = nxt[d][j];
         }
-        if (AHEAD && t0 + 64 < T) fetch(t0 + 64);
+        if (AHEAD && t0 + 64 * DEPTH < T) fetch(nxt[d], avg, t0 + 64 * DEPTH);
         att_chunk row[CPR];
 #pragma unroll
         for (int j = 0; j < CPR; ++j) row[j] = *reinterpret_cast<const att_chunk *>(mytile + lane * TP + j * EPC);
-        f32x2 acc = { 0.0f, 0.0f };
         // (the offset is laundered so that the 2 UP loop-invariant LDS values are re-read per tile instead of
         // living in registers for the whole kernel)
         int qoff = wave * UP * 2;
         asm volatile("" : "+v"(qoff));
         const float *qw = &qs[0][0][0] + qoff;
+        // Eight unit pairs at a time, stage by stage (a transcendental's result is not ready for the very next instruction: with the
+        // stages of one pair back to back the compiler pads every one of them with s_nop), the pairs' constants as they lie in LDS
+        // ({q, q, s, s}: packed operands without a register shuffle), four accumulators instead of one dependent chain
+        f32x2 acc4[4] = { { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f }, { 0.0f, 0.0f } };
 #pragma unroll
         for (int k0 = 0; k0 < UP; k0 += 16) {                // 8 broadcast reads in flight, then 8 unit pairs
             f32x4 qv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) qv[i] = *reinterpret_cast<const f32x4 *>(qw + 2 * (k0 + 2 * i));      // same address in every lane
+            f32x2 x[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = k0 + 2 * i;
                 const f32x2 a = { att_elem<AT>(row, k), att_elem<AT>(row, k + 1) };
-                const f32x2 x = a * C2 + f32x2{ qv[i][0], qv[i][2] };
-                const f32x2 r = rcp1p_exp2_pair(x.x, x.y);
-                acc = r * f32x2{ qv[i][1], qv[i][3] } + acc;
+                x[i] = a * C2 + f32x2{ qv[i][0], qv[i][1] };
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = f32x2{ __builtin_amdgcn_exp2f(x[i].x), __builtin_amdgcn_exp2f(x[i].y) };
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = x[i] + 1.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = f32x2{ __builtin_amdgcn_rcpf(x[i].x), __builtin_amdgcn_rcpf(x[i].y) };
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc4[i & 3] = x[i] * f32x2{ qv[i][2], qv[i][3] } + acc4[i & 3];
         }
+        const f32x2 acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
         const float et = ok ? ssum + acc.x + acc.y : -INFINITY;
         const float new_m = fmaxf(run_m, wave_allmax(et));
         const float alpha = __builtin_amdgcn_exp2f(1.4426950408889634f * (run_m - new_m));      // 0 on the first tile
@@ -984,7 +1039,24 @@ __global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? 1 : 2) at
             const f32x2 c = f32x2{ ctx[k], ctx[k + 1] } * alpha + a * pt;
             ctx[k] = c.x; ctx[k + 1] = c.y;
         }
+      }
     }
+    // ---- this window's stored logit halves (all of them, if they fit the registers set aside), then the NEXT window's first loads:
+    // both are in flight during the butterfly, and the loads return in order, so the output phase below waits for the first only
+    const float *pl = p.pl + wl * (int64_t)T * C;
+    const bool hoist = PCH > 0 && T <= 64 * PCH;
+    float ph[PCH > 0 ? PCH : 1][CM];
+    if (hoist) {
+#pragma unroll
+        for (int ch = 0; ch < PCH; ++ch) {
+            const int t = min(lane + 64 * ch, T - 1);
+            if (64 * ch < T) {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) ph[ch][c] = pl[(int64_t)t * C + (c < C ? c : C - 1)];
+            }
+        }
+    }
+    if (PIPE && wi + 4 < nvalid) start_window(wl + 4);
     // ---- butterfly: lane l ends with the window's context for unit l (and unit l + 64 when CT = 128).
     // xor 32 / xor 16: v_permlane32_swap / v_permlane16_swap exchange exactly the halves (rows) the two partners
     // discard, so "kept + received" is one swap and one add; xor 8, 2, 1 are DPP moves; xor 4 has none on gfx9.
@@ -1031,36 +1103,24 @@ __global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? 1 : 2) at
         }
     }
     const float inv = __builtin_amdgcn_rcpf(run_l);
-    float ctop[16];
+    float ctop[CM];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        float part = 0.0f;
-        if (c < C) {
-            if (lane < UP) part = ctx[0] * p.wtop[lane * 16 + c];
-            if (CT == 128 && lane + 64 < UP) part += ctx[64] * p.wtop[(lane + 64) * 16 + c];
-            part = wave_allsum(part) * inv;
-        }
-        ctop[c] = part;
+    for (int c = 0; c < CM; ++c) {
+        float part = ctx[0] * wt[0][c];
+        if constexpr (CT == 128) part += ctx[64] * wt[QN - 1][c];
+        ctop[c] = wave_allsum(part) * inv;
     }
     // ---- logits[t] = ctx.W_top + (avg[t].W_bot + b), softmax over classes, merge / store: lane <-> t
     int64_t limit = p.n;
     const int64_t row0 = p.merge ? att_window_row(p, wl, &limit) : wl * (int64_t)T;
     const int off = p.merge && row0 >= lo && row0 - lo + T <= p.ospan ? (int)(row0 - lo) : -1;
-    const float *pl = p.pl + wl * (int64_t)T * C;
     // Straight-line over a compile-time class bound (addresses clamped, surplus classes at -inf): with a runtime
     // class loop every load sat in its own basic block and was waited for on its own -- five HBM latencies per tile.
-    // The next tile's stored logit halves are requested before this tile's are used.
-    float pn[CM];
-#pragma unroll
-    for (int c = 0; c < CM; ++c) pn[c] = pl[(int64_t)(lane < T ? lane : 0) * C + (c < C ? c : C - 1)];
-    for (int t = lane; t < T; t += 64) {
+    auto finish = [&](int t, const float (&pv)[CM]) {
         float lg[CM];
         float mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < CM; ++c) { lg[c] = c < C ? pn[c] + ctop[c] : -INFINITY; mx = fmaxf(mx, lg[c]); }
-        const int tn = t + 64 < T ? t + 64 : t;
-#pragma unroll
-        for (int c = 0; c < CM; ++c) pn[c] = pl[(int64_t)tn * C + (c < C ? c : C - 1)];
+        for (int c = 0; c < CM; ++c) { lg[c] = c < C ? pv[c] + ctop[c] : -INFINITY; mx = fmaxf(mx, lg[c]); }
         float den = 0.0f;
 #pragma unroll
         for (int c = 0; c < CM; ++c) { lg[c] = __builtin_amdgcn_exp2f(1.4426950408889634f * (lg[c] - mx)); den += lg[c]; }
@@ -1074,6 +1134,25 @@ __global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? 1 : 2) at
                 else if (off >= 0) lds_atomic_max(obuf + (off + t) * C + c, __float_as_uint(v));
                 else global_atomic_max(reinterpret_cast<unsigned *>(p.out) + (row0 + t) * C + c, __float_as_uint(v));
             }
+    };
+    if (hoist) {
+#pragma unroll
+        for (int ch = 0; ch < PCH; ++ch)
+            if (lane + 64 * ch < T) finish(lane + 64 * ch, ph[ch]);
+    } else {
+        // (windows of more than 512 steps, more than 8 classes: chunk by chunk, the next chunk requested before this one is used)
+        float pn[CM];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) pn[c] = pl[(int64_t)(lane < T ? lane : 0) * C + (c < C ? c : C - 1)];
+        for (int t = lane; t < T; t += 64) {
+            float pv[CM];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) pv[c] = pn[c];
+            const int tn = t + 64 < T ? t + 64 : t;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) pn[c] = pl[(int64_t)tn * C + (c < C ? c : C - 1)];
+            finish(t, pv);
+        }
     }
   }
     if (p.merge && p.ospan > 0) {
@@ -1204,6 +1283,19 @@ static bool split2_applies(const dgrp_model *m) { return m->NW == 4 && m->d_pack
 // gru_wave_kernel (gru_wave.hip): GRU up to 64 units; four waves' carves and the table must fit the CU's LDS -- a property of the model's
 // window and step, never of the record
 static bool wave_applies(const dgrp_model *m) { return m->cell == 0 && m->NU16 > 0 && m->d_packw && !getenv("DGRP_SPLIT_ONE_TILE"); }
+static int wave_try(const dgrp_model *m, gru_params &p, int mode, int64_t s);
+// Row length (elements) of the avg[t] spill between the attention pre-pass and the second kernel: the pre-pass kernel's unit padding --
+// 16 NU for gru_wave_kernel (a 36-unit model spills 48 floats per step, not 64), the model's UP (multiple of 32) otherwise.  A property
+// of the model and its precision level only: the pre-pass never needs an image, so whether four waves' carves fit depends on T alone.
+int dgrp_spill_row(const dgrp_model *m)
+{
+    if (m->precision == 1 && m->cell == 0 && m->NU16 > 0 && m->d_packw && !getenv("DGRP_SPLIT_ONE_TILE")) {
+        gru_params q;
+        q.T = m->T; q.C = m->C; q.Tp = (int)dgrp_align_up(m->T, 16);
+        if (wave_try(m, q, 2, 1)) return 16 * m->NU16;
+    }
+    return m->UP;
+}
 static int wave_try(const dgrp_model *m, gru_params &p, int mode, int64_t s)
 {
     const int64_t budget = (160 * 1024 - dgrp_wave_table_bytes(m->NU16)) / 4 / 16 * 16;
@@ -1237,7 +1329,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     const bool split = use_split(m, mode);
     p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
     p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0; p.stream = m->d_stream;
-    p.packw = m->d_packw; p.xtabw = m->d_xtabw; p.avg_up = m->UP;
+    p.packw = m->d_packw; p.xtabw = m->d_xtabw; p.avg_up = dgrp_spill_row(m);
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
     if (split && wave_applies(m)) {
@@ -1320,7 +1412,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     const bool split = use_split(m, mode);
     p.pack_lo = m->d_pack_lo; p.zfold = m->onercp ? 1.0f : 0.0f;
     p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0; p.stream = m->d_stream;
-    p.packw = m->d_packw; p.xtabw = m->d_xtabw; p.avg_up = m->UP;
+    p.packw = m->d_packw; p.xtabw = m->d_xtabw; p.avg_up = dgrp_spill_row(m);
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
     if (split && wave_applies(m)) {
         if (const int wb = wave_try(m, p, mode, s)) return dgrp_wave_launch(p, m->NU16, total_groups, wb, m->onercp != 0, stream);
@@ -1373,8 +1465,9 @@ int dgrp_attention_launch_recs(const dgrp_model *m, int64_t s, dgrp_placement pl
     att_params p;
     p.avg = d_avg; p.pl = d_pl; p.scale = m->d_scale; p.wtop = m->d_wtop; p.out = d_out;
     p.n = n; p.s = s; p.w0 = w0; p.nw = nw; p.place = place;
-    p.T = m->T; p.C = m->C; p.UP = m->UP; p.merge = merge;
+    p.T = m->T; p.C = m->C; p.UP = dgrp_spill_row(m); p.merge = merge;
     p.recs = (const gru_rec *)d_recs; p.nrec = nrec;
+    const int UPs = p.UP;                                     // row length of the spill: the pre-pass kernel's unit padding
     // element type of the avg[t] spill: fp32 behind a split-operand pre-pass (the level the model is set to), else fp16
     const bool f32 = m->precision == 1;
     const int esz = f32 ? 4 : 2;
@@ -1382,32 +1475,44 @@ int dgrp_attention_launch_recs(const dgrp_model *m, int64_t s, dgrp_placement pl
     p.ospan = 0;
     const int64_t want = (ATT_WPB - 1) * s + m->T;
     const unsigned grid = (unsigned)((nw + ATT_WPB - 1) / ATT_WPB);
-    if (m->UP <= 64) {
+    if (UPs <= 64) {
         // one wave per window; beyond 64 units its per-lane context (UP registers) no longer fits beside the row
-        const int stat = 4 * m->UP * 2 * 4 + 4 * 64 * (m->UP + 16 / esz) * esz;  // qs + tiles (static LDS of the kernel)
+        const int stat = 4 * UPs * 2 * 4 + 4 * 64 * (UPs + 16 / esz) * esz;  // qs + tiles (static LDS of the kernel)
         if (merge) {
-            const int64_t budget = stat <= 40 * 1024 ? 78 * 1024 : 156 * 1024;   // two workgroups per CU where the tiles leave room
+            const int64_t budget = (stat <= 40 * 1024 && !f32) || DGRP_ATT_OCC == 2 ? 78 * 1024 : 156 * 1024;   // two workgroups per CU where tiles and registers leave room
             const int64_t cap = (budget - stat) / (m->C * 4);
             p.ospan = (int)(want < cap ? want : cap);
             if (p.ospan < m->T) p.ospan = 0;
         }
         const size_t dyn = (size_t)p.ospan * m->C * 4;
-        static bool configured = false;
-        if (!configured) {                                   // static + dynamic LDS may use the whole 160 KiB
-#define ATT_CFG(UPv, CMv, ATv) DGRP_HIP(hipFuncSetAttribute((const void *)attention_wave_kernel<UPv, CMv, ATv>, \
-        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (4 * UPv * 8 + 256 * (UPv + (int)(16 / sizeof(ATv))) * (int)sizeof(ATv))))
+        static std::once_flag configured;
+        static hipError_t cfg_err = hipSuccess;
+        std::call_once(configured, [] {                          // static + dynamic LDS may use the whole 160 KiB
+#define ATT_CFG(UPv, CMv, ATv) do { hipError_t e_ = hipFuncSetAttribute((const void *)attention_wave_kernel<UPv, CMv, ATv>, \
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (4 * UPv * 8 + 256 * (UPv + (int)(16 / sizeof(ATv))) * (int)sizeof(ATv))); \
+        if (e_ != hipSuccess) cfg_err = e_; } while (0)
             ATT_CFG(32, 8, _Float16); ATT_CFG(32, 16, _Float16); ATT_CFG(64, 8, _Float16); ATT_CFG(64, 16, _Float16);
             ATT_CFG(32, 8, float); ATT_CFG(32, 16, float); ATT_CFG(64, 8, float); ATT_CFG(64, 16, float);
+            ATT_CFG(16, 8, float); ATT_CFG(16, 16, float); ATT_CFG(48, 8, float); ATT_CFG(48, 16, float);
 #undef ATT_CFG
-            configured = true;
-        }
+        });
+        DGRP_HIP(cfg_err);
 #define ATT_GO(UPv, CMv) do { if (f32) hipLaunchKernelGGL((attention_wave_kernel<UPv, CMv, float>), dim3(grid), dim3(256), dyn, stream, p); \
                               else hipLaunchKernelGGL((attention_wave_kernel<UPv, CMv, _Float16>), dim3(grid), dim3(256), dyn, stream, p); } while (0)
-        if (m->UP == 32 && m->C <= 8) ATT_GO(32, 8);
-        else if (m->UP == 32) ATT_GO(32, 16);
+#define ATT_GO32(UPv, CMv) hipLaunchKernelGGL((attention_wave_kernel<UPv, CMv, float>), dim3(grid), dim3(256), dyn, stream, p)
+        if (UPs == 16 || UPs == 48) {                            // rows of 16 / 48 floats: only gru_wave_kernel writes them (fp32 spill)
+            DGRP_REQUIRE(f32, "attention: a %d-unit spill row is fp32", UPs);
+            if (UPs == 16 && m->C <= 8) ATT_GO32(16, 8);
+            else if (UPs == 16) ATT_GO32(16, 16);
+            else if (m->C <= 8) ATT_GO32(48, 8);
+            else ATT_GO32(48, 16);
+        }
+        else if (UPs == 32 && m->C <= 8) ATT_GO(32, 8);
+        else if (UPs == 32) ATT_GO(32, 16);
         else if (m->C <= 8) ATT_GO(64, 8);
         else ATT_GO(64, 16);
 #undef ATT_GO
+#undef ATT_GO32
         DGRP_LAUNCH_CHECK();
         return DGRP_OK;
     }

@@ -382,7 +382,8 @@ __device__ __forceinline__ void split_hi_lo4(const float h[4], uint2 &hv, uint2 
 __device__ __forceinline__ float wave_half_sum(float h)
 {
 #pragma clang fp contract(off)
-    const float other = row_ror<8>(h);
+    // (old = the value itself: a rotation fills every lane, and with a zero `old` the compiler spends a v_mov on the fill)
+    const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h), __builtin_bit_cast(int, h), 0x128, 0xf, 0xf, false));
     const float half = 0.5f * h;
     return __builtin_fmaf(0.5f, other, half);
 }
