@@ -380,10 +380,13 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
         }
         if (u <= 64) {
             // gru_wave_kernel's operands (gru_wave.hip): every wave holds ALL units.  A fragment of v_mfma_f32_16x16x32_f16: lane l, element j
-            // <-> A[row l & 15][k 8 (l >> 4) + j]; here row = unit 16 ug + (l & 15), k = recurrent row 32 ks + 8 (l >> 4) + j.  Dense B fragment:
-            // lane l, element j <-> B[k 8 (l >> 4) + j][column l & 15] = 0.5 * FF kernel[row0 + 32 ks + k][class].  Same scaled values and
+            // <-> A[row l & 15][k 8 (l >> 4) + j]; here row = unit 16 ug + (l & 15), k = tile column 32 ks + 8 (l >> 4) + j.  Dense B fragment:
+            // lane l, element j <-> B[k 8 (l >> 4) + j][column l & 15] = 0.5 * FF kernel[row0 + unit of tile column 32 ks + k][class].  Same scaled values and
             // hi/lo split as the other split-operand kernels.
             const int NU = (u + 15) / 16, KSw = (NU + 1) / 2, UP16 = 16 * NU, NFw = 6 * KSw * NU;
+            // column c of the kernel's hidden tile holds unit wave_col(c): inside every 32 columns the 4 units a lane owns of unit group
+            // 2 j and of group 2 j + 1 alternate (the kernel publishes them with one 16-byte store)
+            auto wave_col = [](int c) { const int j = c / 32, q = (c % 32) / 8, sub = c % 8; return 16 * (2 * j + (sub >= 4 ? 1 : 0)) + 4 * q + (sub & 3); };
             static const int orderw[3] = { 1, 2, 0 };                                   // r, g, z in Keras column blocks [z | r | h]
             std::vector<uint16_t> pw((size_t)(NFw + 2 * KSw) * 64 * 8, 0);
             for (int gi = 0; gi < 3; ++gi)
@@ -391,7 +394,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
                     for (int ug = 0; ug < NU; ++ug)
                         for (int l = 0; l < 64; ++l)
                             for (int j = 0; j < 8; ++j) {
-                                const int g = orderw[gi], unit = 16 * ug + (l & 15), k = 32 * ks + 8 * (l >> 4) + j;
+                                const int g = orderw[gi], unit = 16 * ug + (l & 15), k = wave_col(32 * ks + 8 * (l >> 4) + j);
                                 if (unit >= u || k >= u) continue;
                                 const float gs = g < 2 ? -1.4426950408889634f : 2.8853900817779268f;
                                 const float x = gs * rec[(size_t)k * u3 + g * u + unit];
@@ -403,7 +406,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
             for (int ks = 0; ks < KSw; ++ks)
                 for (int l = 0; l < 64; ++l)
                     for (int j = 0; j < 8; ++j) {
-                        const int k = 32 * ks + 8 * (l >> 4) + j, c = l & 15;
+                        const int k = wave_col(32 * ks + 8 * (l >> 4) + j), c = l & 15;
                         if (k >= u || c >= C) continue;
                         const float v = 0.5f * ffk[(size_t)(drow0 + k) * C + c];
                         const uint16_t hi = f2h(v);

@@ -889,6 +889,12 @@ __device__ __forceinline__ float att_elem(const att_chunk (&row)[N], int k)
 #ifndef DGRP_ATT_OCC
 #define DGRP_ATT_OCC 1
 #endif
+#ifndef DGRP_ATT_PIPE_MINUP
+#define DGRP_ATT_PIPE_MINUP 48
+#endif
+#ifndef DGRP_ATT_DEPTH2_MINUP
+#define DGRP_ATT_DEPTH2_MINUP 48
+#endif
 template <int UP, int CM, typename AT>
 __global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? DGRP_ATT_OCC : 2) attention_wave_kernel(const att_params p)
 {
@@ -917,10 +923,10 @@ __global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? DGRP_ATT_
     constexpr int CPR = UP / EPC, TP = UP + EPC;             // 16-byte chunks per row, LDS row pitch
     AT *mytile = &tile[wave][0][0];
     // Tiles in flight per wave, in registers: with the 512-register budget of a lone wave a second tile ahead is free.
-    constexpr int DEPTH = (sizeof(AT) == 4 && UP <= 64 && DGRP_ATT_OCC == 1) ? 2 : 1;
+    constexpr int DEPTH = (sizeof(AT) == 4 && UP <= 64 && UP >= DGRP_ATT_DEPTH2_MINUP && DGRP_ATT_OCC == 1) ? 2 : 1;
     constexpr bool AHEAD = UP * sizeof(AT) <= 128 || UP <= 64;   // beyond 64 units the registers for a tile in flight are gone
     constexpr int QN = (UP + 63) / 64;                       // units per lane of a window's q row (k = lane, lane + 64)
-    constexpr bool PIPE = sizeof(AT) == 4 && UP <= 64 && DGRP_ATT_OCC == 1;   // a lone wave per SIMD: registers to spare for the next window's first loads
+    constexpr bool PIPE = sizeof(AT) == 4 && UP <= 64 && UP >= DGRP_ATT_PIPE_MINUP && DGRP_ATT_OCC == 1;   // a lone wave per SIMD: registers to spare for the next window's first loads
     constexpr int PCH = (CM <= 8 && PIPE) ? 8 : 0;           // 64-step chunks of stored logit halves kept in registers (T <= 512)
     att_chunk nxt[DEPTH][CPR];
     auto fetch = [&](att_chunk (&dst)[CPR], const AT *avg, int t0) {
@@ -1282,14 +1288,20 @@ static int64_t tile_budget(const dgrp_model *m, bool split)
 static bool split2_applies(const dgrp_model *m) { return m->NW == 4 && m->d_pack16 && !getenv("DGRP_SPLIT_ONE_TILE"); }
 // gru_wave_kernel (gru_wave.hip): GRU up to 64 units; four waves' carves and the table must fit the CU's LDS -- a property of the model's
 // window and step, never of the record
-static bool wave_applies(const dgrp_model *m) { return m->cell == 0 && m->NU16 > 0 && m->d_packw && !getenv("DGRP_SPLIT_ONE_TILE"); }
+// (17-32 units as an attention pre-pass: the one-wave workgroups of gru_split_kernel<1> -- no partner wave to meet either -- measured 5-7 %
+// faster than two unit groups here, r03 `tools/bench_shapes.py`; every other count of unit groups and every merged / window-output launch
+// is faster on this kernel)
+static bool wave_applies(const dgrp_model *m, int mode)
+{
+    return m->cell == 0 && m->NU16 > 0 && m->d_packw && !(m->NU16 == 2 && mode == 2) && !getenv("DGRP_SPLIT_ONE_TILE");
+}
 static int wave_try(const dgrp_model *m, gru_params &p, int mode, int64_t s);
 // Row length (elements) of the avg[t] spill between the attention pre-pass and the second kernel: the pre-pass kernel's unit padding --
 // 16 NU for gru_wave_kernel (a 36-unit model spills 48 floats per step, not 64), the model's UP (multiple of 32) otherwise.  A property
 // of the model and its precision level only: the pre-pass never needs an image, so whether four waves' carves fit depends on T alone.
 int dgrp_spill_row(const dgrp_model *m)
 {
-    if (m->precision == 1 && m->cell == 0 && m->NU16 > 0 && m->d_packw && !getenv("DGRP_SPLIT_ONE_TILE")) {
+    if (m->precision == 1 && wave_applies(m, 2)) {
         gru_params q;
         q.T = m->T; q.C = m->C; q.Tp = (int)dgrp_align_up(m->T, 16);
         if (wave_try(m, q, 2, 1)) return 16 * m->NU16;
@@ -1332,7 +1344,7 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     p.packw = m->d_packw; p.xtabw = m->d_xtabw; p.avg_up = dgrp_spill_row(m);
     const int64_t groups = (nw + DGRP_WG_WINDOWS - 1) / DGRP_WG_WINDOWS;
     DGRP_REQUIRE(groups < (1ll << 31), "too many windows in one launch (%lld)", (long long)nw);
-    if (split && wave_applies(m)) {
+    if (split && wave_applies(m, mode)) {
         if (const int wb = wave_try(m, p, mode, s)) return dgrp_wave_launch(p, m->NU16, groups, wb, m->onercp != 0, stream);
     }
     if (split && split2_applies(m)) {
@@ -1414,7 +1426,7 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     p.pack16 = m->d_pack16; p.xtab = m->d_xtab; p.xtab_off = 0; p.stream = m->d_stream;
     p.packw = m->d_packw; p.xtabw = m->d_xtabw; p.avg_up = dgrp_spill_row(m);
     DGRP_REQUIRE(total_groups < (1ll << 31), "too many windows in one launch");
-    if (split && wave_applies(m)) {
+    if (split && wave_applies(m, mode)) {
         if (const int wb = wave_try(m, p, mode, s)) return dgrp_wave_launch(p, m->NU16, total_groups, wb, m->onercp != 0, stream);
     }
     if (split && split2_applies(m)) {

@@ -378,14 +378,15 @@ __device__ __forceinline__ void split_hi_lo4(const float h[4], uint2 &hv, uint2 
 }
 
 // attention pre-pass of gru_wave_kernel: (h + h of the other strand) / 2, the other strand's row sitting 8 lanes away in the same DPP
-// row of 16 -- one rounding (halving is exact), the value of rounding the sum and halving it
-__device__ __forceinline__ float wave_half_sum(float h)
+// row of 16 -- one rounding (halving is exact), the value of rounding the sum and halving it.  Two instructions: h / 2, then
+// v_fmac_f32_dpp adds the rotated h times 1/2 (through the builtin the compiler spent two v_mov per value on the rotation; the
+// s_nop covers the VALU-write -> DPP-read hazard the assembler does not see).  `half` = a register holding 0.5.
+__device__ __forceinline__ float wave_half_sum(float h, float half)
 {
 #pragma clang fp contract(off)
-    // (old = the value itself: a rotation fills every lane, and with a zero `old` the compiler spends a v_mov on the fill)
-    const float other = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h), __builtin_bit_cast(int, h), 0x128, 0xf, 0xf, false));
-    const float half = 0.5f * h;
-    return __builtin_fmaf(0.5f, other, half);
+    float t = half * h;
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(h), "v"(half));
+    return t;
 }
 
 // LSTM cell update of one (row, unit) for the split-operand kernel, every a*b+c an explicit fma and nothing left to contract, so

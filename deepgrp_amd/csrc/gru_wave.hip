@@ -14,7 +14,8 @@
 //     convoy kept the matrix phases and the gate phases of a SIMD's waves aligned: matrix pipe 41 % busy, each wave issuing a third
 //     of the time).  A workgroup is four such waves (one per SIMD, 512-register budget) that share nothing but the input table.
 //   * D[unit][row]: a lane holds 4 consecutive units per unit group of ONE row (window lane & 7, strand (lane >> 3) & 1), so the gate
-//     math is lane-local and a publish is one 8-byte store per unit group and half.  One LDS tile per row tile and half, no
+//     math is lane-local and a publish is one 16-byte store per PAIR of unit groups and half (the hidden tile's columns are permuted so
+//     that a lane's units of two groups lie side by side; the packed weights follow the permutation).  One LDS tile per row tile and half, no
 //     ping-pong: a tile's fragments are read in its MFMA phase and rewritten in its epilogue phase, in program order of one wave.
 //   * Dense: the hidden tile's B fragments of the recurrent MFMAs ARE the A fragments of the Dense product (same lane map), so the
 //     Dense layer costs 3 MFMAs per k-step and no LDS read; the result holds the forward rows' and the reverse-complement rows'
@@ -121,8 +122,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int cls = lane & 15;
     const float fbias = cls < C ? pin.ffb[cls] : 0.0f;
     const unsigned frag_lane = (unsigned)(row * HS + 8 * q4) * 2;       // fragment: tile row `row`, k = 8 q4 .. (+ 64 B per k-step)
-    const unsigned pub_lane = (unsigned)(row * HS + 4 * q4) * 2;        // publish: units 16 ug + 4 q4 .. of tile row `row` (+ 32 B per unit group)
+    // publish: the lane's 4 units of unit group 2 j and its 4 units of group 2 j + 1 go side by side into columns 32 j + 8 q4 .. + 7 --
+    // the 16 bytes its own k-step-j fragment reads (ONE ds_write_b128 per pair of groups and half instead of two ds_write_b64 that
+    // were 4-way bank conflicts at this row pitch: 12 % of the kernel's cycles in SQ_LDS_BANK_CONFLICT).  The recurrent and Dense
+    // fragments are packed in that column order (api.hip, dgrp_wave_col).
     const unsigned tab_lane = (unsigned)(4 * q4) * 4;                   // table: the same 4 units (+ 64 B per unit group, + 4 UP16 B per kind)
+    float vhalf = 0.5f;
+    asm volatile("" : "+v"(vhalf));                                     // a register operand of v_fmac_f32_dpp (wave_half_sum)
     const uint32_t comp_xor = rc ? 3u : 0u;                             // complement [3, 2, 1, 0, 4] (model.py:233-237) = b ^ 3 for b < 4
 
     // ---- the wave's group of 16 windows: LDS carve, staged sequences, placement (what wg_setup does for a workgroup)
@@ -268,9 +274,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             split_residual4(pbh[g], pbhv[g]);                                                                    \
         } else if constexpr ((op) == 3) {                                                                        \
             pblv[g] = split_pack4(pbh[g]);                                                                       \
-        } else {                                                                                                 \
-            *reinterpret_cast<uint2 *>(smem + Y.hbuf + pub_lane + (g) * 32) = pbhv[g];                           \
-            *reinterpret_cast<uint2 *>(smem + Y.lbuf + pub_lane + (g) * 32) = pblv[g];                           \
+        } else if constexpr ((g) % 2 == 1) {     /* a pair of unit groups: 16 bytes per lane and half (column order: dgrp_wave_col) */ \
+            *reinterpret_cast<uint4 *>(smem + Y.hbuf + frag_lane + ((g) / 2) * 64) = make_uint4(pbhv[(g) - 1].x, pbhv[(g) - 1].y, pbhv[g].x, pbhv[g].y); \
+            *reinterpret_cast<uint4 *>(smem + Y.lbuf + frag_lane + ((g) / 2) * 64) = make_uint4(pblv[(g) - 1].x, pblv[(g) - 1].y, pblv[g].x, pblv[g].y); \
+        } else if constexpr ((g) == NU - 1) {    /* the last group of an odd count on its own */                  \
+            *reinterpret_cast<uint2 *>(smem + Y.hbuf + frag_lane + ((g) / 2) * 64) = pbhv[g];                    \
+            *reinterpret_cast<uint2 *>(smem + Y.lbuf + frag_lane + ((g) / 2) * 64) = pblv[g];                    \
         }                                                                                                        \
     }
         // attention pre-pass: avg[ty] of unit group g = (h_fwd + h_rc) / 2 from the fp32 state (pbh[g] holds h between PB 0 and PB 2);
@@ -278,7 +287,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #define AV(g, op)                                                                                                \
     if constexpr (DO_Y && MODE == 2) {                                                                           \
         if constexpr ((op) == 0) {                                                                               \
-            avv[g] = f32x4{ wave_half_sum(pbh[g][0]), wave_half_sum(pbh[g][1]), wave_half_sum(pbh[g][2]), wave_half_sum(pbh[g][3]) }; \
+            avv[g] = f32x4{ wave_half_sum(pbh[g][0], vhalf), wave_half_sum(pbh[g][1], vhalf), wave_half_sum(pbh[g][2], vhalf), wave_half_sum(pbh[g][3], vhalf) }; \
         } else if (Y.avg_off >= 0) {                                                                             \
             *reinterpret_cast<f32x4 *>(abase + Y.avg_off + ty * p.avg_up + 16 * (g)) = avv[g];                   \
             if constexpr ((g) == NU - 1 && (NU & 1)) {                                                           \

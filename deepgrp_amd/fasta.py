@@ -288,17 +288,15 @@ def ingest_ranges(path: Union[str, os.PathLike], ranges=None, group_bytes: int =
         ranges = [(0, size)]
     # ACCESS_COPY: a private, writable mapping (never written) so that torch accepts views of it
     with open(path, "rb") as fh, mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_COPY) as mm:
-        whole = np.frombuffer(mm, dtype=np.uint8)
-        try:
-            for a, b in ranges:
-                if not (0 <= a < b <= size) or (a and not (mm[a] == 62 and mm[a - 1] == 10)):
-                    raise ValueError(f"{path}: [{a}, {b}) is not a range of whole chunks")
-                yield from _ingest_range(L, dev, path, mm, whole, a, b, group_bytes, group_records)
-        finally:
-            del whole                                   # release the buffer export before the mmap closes
+        for a, b in ranges:
+            if not (0 <= a < b <= size) or (a and not (mm[a] == 62 and mm[a - 1] == 10)):
+                raise ValueError(f"{path}: [{a}, {b}) is not a range of whole chunks")
+            # (no numpy view of the mapping outlives a statement in there: an exception of the reference loop -- the blank line's
+            # IndexError -- must find the mapping free of exported buffers when it unwinds through this `with`)
+            yield from _ingest_range(L, dev, path, mm, a, b, group_bytes, group_records)
 
 
-def _ingest_range(L, dev, path, mm, whole, r0: int, r1: int, group_bytes: int, group_records: int):
+def _ingest_range(L, dev, path, mm, r0: int, r1: int, group_bytes: int, group_records: int):
     """ingest_ranges for one range [r0, r1) of the mapped file; offsets below are relative to r0 unless they say `abs`."""
     import numpy as np
     import torch
@@ -321,7 +319,7 @@ def _ingest_range(L, dev, path, mm, whole, r0: int, r1: int, group_bytes: int, g
         # chunk table in numpy (a file of 100 000 records would otherwise spend its time in per-record find()s):
         # chunk starts = range start and every '>' that follows a line feed; end of each chunk's first line
         blk = 1 << 28                                                  # bounded temporaries on multi-GB files
-        part = whole[r0:r1]
+        part = np.frombuffer(mm, dtype=np.uint8, count=size, offset=r0)
         lf_pos = np.concatenate([np.flatnonzero(part[o:o + blk] == 10) + o for o in range(0, size, blk)] or [np.zeros(0, np.int64)])
         nxt = lf_pos + 1
         nxt = nxt[nxt < size]
@@ -360,7 +358,7 @@ def _ingest_range(L, dev, path, mm, whole, r0: int, r1: int, group_bytes: int, g
             else:
                 UPLOAD_STATS["bytes"] += g1 - g0
                 UPLOAD_STATS["uploads"] += 1
-                d_raw = torch.from_numpy(whole[r0 + g0:r0 + g1]).to(dev)
+                d_raw = torch.from_numpy(np.frombuffer(mm, dtype=np.uint8, count=g1 - g0, offset=r0 + g0)).to(dev)
             d_idx = torch.empty(g1 - g0, dtype=torch.uint8, device=dev)
             off = np.array([body0s[i] - g0 for i in range(c1 - c0)], np.int64)
             ln = np.array([(starts[c0 + i + 1] - body0s[i]) if cand[i] else 0 for i in range(c1 - c0)], np.int64)

@@ -28,7 +28,11 @@ cases = [("defaults.toml  u=60  T=342 s=50 attention", 60, 342, 50, True, 20e6),
          ("               u=40  T=200 s=50", 40, 200, 50, False, 20e6),
          ("               u=44  T=200 s=50", 44, 200, 50, False, 20e6),
          ("               u=48  T=200 s=50", 48, 200, 50, False, 20e6),
-         ("               u=16  T=200 s=50", 16, 200, 50, False, 20e6)]
+         ("               u=16  T=200 s=50", 16, 200, 50, False, 20e6),
+         ("               u=16  T=200 s=50 attention", 16, 200, 50, True, 20e6),
+         ("               u=24  T=200 s=50 attention", 24, 200, 50, True, 20e6),
+         ("               u=48  T=200 s=50 attention", 48, 200, 50, True, 20e6),
+         ("               u=64  T=200 s=50 attention", 64, 200, 50, True, 20e6)]
 only = sys.argv[1] if len(sys.argv) > 1 else ""
 only_split = os.environ.get("SHAPES_SPLIT_ONLY") == "1"
 for name, u, T, s, att, n in cases:
