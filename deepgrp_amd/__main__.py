@@ -94,12 +94,12 @@ class CommandLineParser:
         verify.add_argument("FASTA", nargs="*", type=str, help="Fasta input files; none = a random ACGT sequence")
         verify.add_argument("--windows", type=int, default=256, help="windows to compare per record (spread evenly)")
         predict.add_argument("--fast", action="store_true",
-                             help="(addition) fp16-operand fused kernel for every model: 2-2.5x the default's speed on GRU models up to 128 "
-                                  "units, class probabilities within 1e-3 of fp32 except on ill-conditioned windows "
-                                  "(measure with `verify`)")
+                             help="(addition) fp16-operand fused kernels: 2-2.5x the default's speed, class probabilities within 1e-3 of "
+                                  "fp32 except on ill-conditioned windows (measure with `verify`); the default is fp32-grade (split "
+                                  "operands, 1e-5) for every model")
         predict.add_argument("--precise", action="store_true",
-                             help="(addition) plain-fp32 forward pass for the models the split-operand kernel does not cover completely "
-                                  "(attention, LSTM, > 128 units), about 30 Mbp/s")
+                             help="(addition, kept for compatibility) the default: since every model has an fp32-grade fused kernel "
+                                  "this flag selects nothing else")
         predict.add_argument("--split_contigs", action="store_true",
                              help="multi-GPU only: spread the windows of EVERY record over all GPUs (for a few huge "
                                   "records) instead of sharding whole records")
@@ -176,10 +176,8 @@ class CommandLineParser:
         pipe = ContigPipeline(model, args.step_size, options.batch_size, options.min_mss_len, options.xdrop_len,
                               use_mss=not args.no_use_mss, precise=getattr(args, "precise", False),
                               fast=getattr(args, "fast", False))
-        _LOG.info("Forward kernel: %s", "plain fp32 kernels (--precise)" if pipe.fp32 else
-                  "fused, split operands (fp32-grade)" if pipe.split else "fused, fp16 operands")
-        if pipe.fp32 and getattr(args, "split_contigs", False):
-            sys.exit("--precise is not combined with --split_contigs for this model")      # same verdict on every rank, before any collective
+        _LOG.info("Forward kernel: %s", "plain fp32 kernels (more units than the fused kernels take)" if getattr(model, "fp32_only", False)
+                  else "fused, split operands (fp32-grade)" if pipe.split else "fused, fp16 operands")
         outstream = None
         if rank == 0:
             outstream = sys.stdout if args.output == "-" else open(args.output, "w")

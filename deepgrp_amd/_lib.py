@@ -42,6 +42,7 @@ _SIGNATURES = {
     "dgrp_model_dims": (cint, [vp, C.POINTER(cint), C.POINTER(cint), C.POINTER(cint), C.POINTER(cint)]),
     "dgrp_model_flags": (cint, [vp]),
     "dgrp_model_set_precision": (cint, [vp, cint]),
+    "dgrp_model_view": (cint, [vp, cint, C.POINTER(vp)]),
     "dgrp_forward_workspace_bytes": (i64, [vp, i64]),
     "dgrp_forward_window_chunk": (i64, [vp]),
     "dgrp_forward_windows": (cint, [vp, vp, i64, i64, i64, i64, vp, vp, i64, vp]),

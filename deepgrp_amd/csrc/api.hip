@@ -203,6 +203,28 @@ static hipError_t upload_stream(dgrp_model *m, const float *rec, int G, const fl
     return e;
 }
 
+// Models beyond the fused kernels' sizes: nothing is packed, the fp32 tensors as given are all the device holds, and every forward
+// call goes through ref_kernels.hip (forward_ref below).  The reference builds its RNN layer with any `units`
+// (deepgrp/model.py:117,219-229): such a model is slow here (tens of Mbp/s), not refused.
+static int create_ref_only(dgrp_model **out, dgrp_model *m, const float *kernel, const float *rec, const float *bias, int64_t nbias,
+                           const float *ffk, int64_t nffk, const float *ffb, const float *scale)
+{
+    m->ref_only = 1;
+    m->onercp = 0;
+    m->UP = (m->u + 31) / 32 * 32; m->NW = m->UP / 32; m->KS = m->UP / 16; m->nfrag = 0;
+    m->d_pack = nullptr; m->d_ffb = nullptr; m->d_scale = nullptr; m->d_wtop = nullptr; m->d_raw = nullptr;
+    m->d_pack_lo = nullptr; m->precision = 1; m->d_pack16 = nullptr; m->d_xtab = nullptr; m->d_stream = nullptr;
+    m->d_packw = nullptr; m->d_xtabw = nullptr; m->NU16 = 0;
+    const hipError_t e = upload_raw(m, kernel, rec, bias, nbias, ffk, nffk, ffb, scale);
+    if (e != hipSuccess) {
+        dgrp_set_error("dgrp_model_create: %s", hipGetErrorString(e));
+        dgrp_model_destroy(m);
+        return DGRP_EHIP;
+    }
+    *out = m;
+    return DGRP_OK;
+}
+
 DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *kernel,
                                   const float *rec, const float *bias, const float *scale, const float *ffk,
                                   const float *ffb)
@@ -210,7 +232,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     DGRP_REQUIRE(out, "dgrp_model_create: NULL out");
     *out = nullptr;
     DGRP_REQUIRE(T >= 1 && T <= 65535, "dgrp_model_create: window size %d out of range", T);
-    DGRP_REQUIRE(u >= 1 && u <= 256, "dgrp_model_create: units=%d not supported (1..256)", u);
+    DGRP_REQUIRE(u >= 1 && u <= 2048, "dgrp_model_create: units=%d not supported (1..2048)", u);
     DGRP_REQUIRE(C >= 2 && C <= 16, "dgrp_model_create: classes=%d not supported (2..16)", C);
     DGRP_REQUIRE(kernel && rec && bias && ffk && ffb && (!attention || scale), "dgrp_model_create: NULL tensor");
     char nm[8];
@@ -220,6 +242,9 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     dgrp_model *m = new dgrp_model();
     m->T = T; m->u = u; m->C = C; m->attention = attention ? 1 : 0;
     m->cell = 0;
+    m->ref_only = 0; m->is_view = 0;
+    if (u > 256) return create_ref_only(out, m, kernel, rec, bias, 2 * 3 * (int64_t)u, ffk, (int64_t)(attention ? 2 : 1) * u * C, ffb,
+                                        attention ? scale : nullptr);
     m->UP = (u + 31) / 32 * 32;
     m->NW = m->UP / 32;
     m->KS = m->UP / 16;
@@ -453,7 +478,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     DGRP_REQUIRE(out, "dgrp_model_create_lstm: NULL out");
     *out = nullptr;
     DGRP_REQUIRE(T >= 1 && T <= 65535, "dgrp_model_create_lstm: window size %d out of range", T);
-    DGRP_REQUIRE(u >= 1 && u <= 128, "dgrp_model_create_lstm: units=%d not supported (1..128)", u);
+    DGRP_REQUIRE(u >= 1 && u <= 2048, "dgrp_model_create_lstm: units=%d not supported (1..2048)", u);
     DGRP_REQUIRE(C >= 2 && C <= 16, "dgrp_model_create_lstm: classes=%d not supported (2..16)", C);
     DGRP_REQUIRE(kernel && rec && bias && ffk && ffb, "dgrp_model_create_lstm: NULL tensor");
     char nm[8];
@@ -461,6 +486,8 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     if (rc != DGRP_OK) return rc;
     dgrp_model *m = new dgrp_model();
     m->T = T; m->u = u; m->C = C; m->attention = 0; m->cell = 1;
+    m->ref_only = 0; m->is_view = 0;
+    if (u > 256) return create_ref_only(out, m, kernel, rec, bias, 4 * (int64_t)u, ffk, (int64_t)u * C, ffb, nullptr);
     m->UP = (u + 31) / 32 * 32;
     m->NW = m->UP / 32;
     m->KS = m->UP / 16;
@@ -509,9 +536,22 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     return DGRP_OK;
 }
 
+DGRP_EXPORT int dgrp_model_view(const dgrp_model *m, int level, dgrp_model **out)
+{
+    DGRP_REQUIRE(m && out, "dgrp_model_view: NULL argument");
+    *out = nullptr;
+    dgrp_model *v = new dgrp_model(*m);
+    v->is_view = 1;
+    const int rc = dgrp_model_set_precision(v, level);
+    if (rc != DGRP_OK) { delete v; return rc; }
+    *out = v;
+    return DGRP_OK;
+}
+
 DGRP_EXPORT int dgrp_model_destroy(dgrp_model *m)
 {
     if (!m) return DGRP_OK;
+    if (m->is_view) { delete m; return DGRP_OK; }
     if (m->d_pack) (void)hipFree(m->d_pack);
     if (m->d_ffb) (void)hipFree(m->d_ffb);
     if (m->d_scale) (void)hipFree(m->d_scale);
@@ -540,13 +580,14 @@ DGRP_EXPORT int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int
 DGRP_EXPORT int dgrp_model_flags(const dgrp_model *m)
 {
     DGRP_REQUIRE(m, "dgrp_model_flags: NULL model");
-    return (m->onercp ? 1 : 0) | (m->precision == 1 ? 2 : 0);
+    return (m->onercp ? 1 : 0) | (m->precision == 1 ? 2 : 0) | (m->ref_only ? 4 : 0);
 }
 
 DGRP_EXPORT int dgrp_model_set_precision(dgrp_model *m, int level)
 {
     DGRP_REQUIRE(m, "dgrp_model_set_precision: NULL model");
     DGRP_REQUIRE(level == 0 || level == 1, "dgrp_model_set_precision: level must be 0 (fp16 operands) or 1 (split operands)");
+    if (m->ref_only) return DGRP_OK;                          // one kernel set: plain fp32 whatever the level
     DGRP_REQUIRE(level == 0 || m->d_pack_lo || m->d_stream, "dgrp_model_set_precision: this model has no split-operand kernel");
     m->precision = level;
     return DGRP_OK;
@@ -554,11 +595,54 @@ DGRP_EXPORT int dgrp_model_set_precision(dgrp_model *m, int level)
 
 // attention keeps avg[t] ([nw,T,UP]: fp32 behind the split-operand pre-pass, fp16 behind the fp16-operand one -- sized for fp32, the
 // level can change between the query and the call) and the avg half of the logits (fp32 [nw,T,C]) between kernels
+// fp32 path: windows per pass of the plain-fp32 kernels (their h_t of both strands is 2 T u floats per window), and the carve
+static int64_t ref_sub_windows(const dgrp_model *m)
+{
+    const int64_t per = 2 * (int64_t)m->T * m->u * 4 + (int64_t)m->T * (m->C + 1) * 4 + 2 * (int64_t)m->u * 4;
+    return std::max<int64_t>(16, std::min<int64_t>(4096, (512ll << 20) / per) / 16 * 16);
+}
+
 DGRP_EXPORT int64_t dgrp_forward_workspace_bytes(const dgrp_model *m, int64_t nw)
 {
     if (!m || nw < 0) return 0;
+    if (m->ref_only) {
+        const int64_t sub = std::min<int64_t>(ref_sub_windows(m), std::max<int64_t>(nw, 1));
+        return dgrp_align_up(dgrp_forward_reference_workspace_bytes(m, sub), 256) + dgrp_align_up(sub * m->T * (int64_t)m->C * 4, 256);
+    }
     if (!m->attention) return 256;
     return dgrp_align_up(nw * m->T * (int64_t)m->UP * 4, 256) + dgrp_align_up(nw * m->T * (int64_t)m->C * 4, 256);
+}
+
+// the forward entry points of a ref_only model: plain-fp32 kernels a few thousand windows at a time; merged output = the reference's own
+// loop (deepgrp/prediction.py:104-110) on runs of windows whose rows are equally spaced (the short last batch sits elsewhere: SURVEY Q2)
+static int forward_ref(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, dgrp_placement place, int64_t w0, int64_t nw,
+                       int merge, float *d_out, void *d_work, int64_t work_bytes, hipStream_t stream)
+{
+    if (work_bytes < dgrp_forward_workspace_bytes(m, nw) || !d_work) {
+        dgrp_set_error("dgrp_forward: this model runs on the fp32 kernels and needs %lld bytes of workspace for %lld windows",
+                       (long long)dgrp_forward_workspace_bytes(m, nw), (long long)nw);
+        return DGRP_ENOMEM;
+    }
+    const int64_t sub = std::min<int64_t>(ref_sub_windows(m), nw);
+    const int64_t ref_bytes = dgrp_align_up(dgrp_forward_reference_workspace_bytes(m, sub), 256);
+    float *probs = (float *)((char *)d_work + ref_bytes);
+    for (int64_t a = w0; a < w0 + nw; a += sub) {
+        const int64_t k = std::min<int64_t>(sub, w0 + nw - a);
+        float *dst = merge ? probs : d_out + (a - w0) * (int64_t)m->T * m->C;
+        int rc = dgrp_forward_windows_reference(m, d_idx, n, s, a, k, dst, d_work, ref_bytes, stream);
+        if (rc) return rc;
+        if (!merge) continue;
+        for (int64_t b = a; b < a + k;) {                             // runs inside one placement regime
+            const int64_t e = (b < place.nfullB && a + k > place.nfullB) ? place.nfullB : a + k;
+            const int64_t row = dgrp_place_row(place, b, s);
+            if (row < n) {
+                rc = dgrp_get_max(d_out + row * m->C, n - row, probs + (b - a) * (int64_t)m->T * m->C, m->T, m->C, s, e - b, stream);
+                if (rc) return rc;
+            }
+            b = e;
+        }
+    }
+    return DGRP_OK;
 }
 
 static int forward_common(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch, int64_t w0,
@@ -577,6 +661,7 @@ static int forward_common(const dgrp_model *m, const uint8_t *d_idx, int64_t n, 
                      (long long)w0, (long long)(w0 + nw), (long long)total);
         place = dgrp_make_placement(total, batch);
     }
+    if (m->ref_only) return forward_ref(m, d_idx, n, s, place, w0, nw, merge, d_out, d_work, work_bytes, stream);
     if (!m->attention) return dgrp_gru_launch(m, d_idx, n, s, place, w0, nw, merge ? 0 : 1, d_out, nullptr, stream);
     if (work_bytes < dgrp_forward_workspace_bytes(m, nw) || !d_work) {
         dgrp_set_error("dgrp_forward: attention model needs %lld bytes of workspace for %lld windows",
@@ -627,6 +712,7 @@ static int64_t spill_cap_bytes()
 
 static int64_t record_window_chunk(const dgrp_model *m)
 {
+    if (m->ref_only) return ref_sub_windows(m);
     if (!m->attention) return 1ll << 20;
     // whole rounds of workgroups where possible: 32 768 windows = 256 CUs x 8 workgroups x 16 windows is a whole number of rounds
     // for every recurrent kernel (8, 4, 2 or 1 workgroups of 16 windows, or one of 32, per CU); below that 4096 = 256 CUs x 16
@@ -786,7 +872,7 @@ DGRP_EXPORT int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, in
     DGRP_REQUIRE(m && nrec >= 0 && s >= 1 && batch >= 1 && cap >= 0 && h_count, "dgrp_predict_batch: bad arguments");
     *h_count = 0;
     if (nrec == 0) return DGRP_OK;
-    DGRP_REQUIRE(m->cell == 0 || (m->cell == 1 && m->NW <= 4), "dgrp_predict_batch: unsupported model");
+    DGRP_REQUIRE(!m->ref_only && (m->cell == 0 || (m->cell == 1 && m->NW <= 8)), "dgrp_predict_batch: unsupported model (fp32 path: record by record)");
     DGRP_REQUIRE(d_idx && h_idx_off && h_n && h_startpos && h_contig && d_work && (cap == 0 || d_records), "dgrp_predict_batch: NULL pointer");
     for (int64_t r = 0; r < nrec; ++r)
         DGRP_REQUIRE(h_n[r] >= 1 && h_idx_off[r] >= 0, "dgrp_predict_batch: record %lld: empty records do not belong in a batch", (long long)r);

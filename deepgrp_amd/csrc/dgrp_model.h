@@ -12,6 +12,9 @@ struct dgrp_model {
     int KS;      // 16-deep k-steps of the recurrent contraction = UP / 16
     int nfrag;   // fragments per wave: 3*(KS+1) gate fragments + x->h~ + dense hi + dense lo
     int precision;    // 0: fused fp16-operand kernel; 1: split-operand kernel where it applies (dgrp_model_set_precision)
+    int is_view;      // dgrp_model_view: shares every device buffer of the model it was made from and frees none of them
+    int ref_only;     // more units than any fused kernel takes (GRU > 256, LSTM > 256): every forward call runs the plain-fp32 kernels
+                      // of ref_kernels.hip (the reference takes any `units`, deepgrp/model.py:117,219-229) -- slow, but not refused
     uint4 *d_pack;    // [NW][nfrag][64] 8 x fp16 per lane
     uint4 *d_pack_lo; // GRU, NW <= 4: [NW][KS][3][64] lo halves of the recurrent fragments (k-step major, gates r, g, z), or NULL
     // GRU, NW == 4 (97-128 units), for gru_split2_kernel (gru_split2.hip): the recurrent kernel as v_mfma_f32_16x16x32_f16 A fragments,

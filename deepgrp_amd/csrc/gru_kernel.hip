@@ -1177,11 +1177,10 @@ __global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? DGRP_ATT_
 template <int NW, int MODE, bool ONERCP>
 static int launch_gru_mode(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
-    static bool configured = false;          // per instantiation; the attribute is per function, not per launch
-    if (!configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_fused_kernel<NW, MODE, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    static std::once_flag configured;        // per instantiation; the attribute is per function, not per launch (records run on a pool of host threads)
+    static hipError_t cfg_err = hipSuccess;
+    std::call_once(configured, [] { cfg_err = hipFuncSetAttribute((const void *)gru_fused_kernel<NW, MODE, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    DGRP_HIP(cfg_err);
     hipLaunchKernelGGL((gru_fused_kernel<NW, MODE, ONERCP>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;
@@ -1212,13 +1211,15 @@ int dgrp_split2_launch(const gru_params &p, int64_t groups, int half_bytes, bool
 template <int NW, bool ONERCP>
 static int launch_split_rcp(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
-    static bool configured = false;
-    if (!configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 0, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 1, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split_kernel<NW, 2, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    static std::once_flag configured;
+    static hipError_t cfg_err = hipSuccess;
+    std::call_once(configured, [] {
+        auto set = [](const void *f) { const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) cfg_err = e; };
+        set((const void *)gru_split_kernel<NW, 0, ONERCP>);
+        set((const void *)gru_split_kernel<NW, 1, ONERCP>);
+        set((const void *)gru_split_kernel<NW, 2, ONERCP>);
+    });
+    DGRP_HIP(cfg_err);
     if (p.mode == 0)
         hipLaunchKernelGGL((gru_split_kernel<NW, 0, ONERCP>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     else if (p.mode == 1)
@@ -1235,17 +1236,24 @@ static int launch_split(const gru_params &p, int64_t groups, size_t lds, hipStre
 }
 
 // split-operand kernel selected (dgrp_model_set_precision) and applicable to this launch
-static bool use_split(const dgrp_model *m, int) { return m->precision == 1 && ((m->cell == 0 && m->NW <= 4 && m->d_pack_lo) || m->d_stream); }
+// (the LSTM cell beyond 128 units has the streamed split-operand kernel only: it runs at either precision level)
+static bool use_split(const dgrp_model *m, int)
+{
+    if (m->cell == 1 && m->NW > 4 && m->d_stream) return true;
+    return m->precision == 1 && ((m->cell == 0 && m->NW <= 4 && m->d_pack_lo) || m->d_stream);
+}
 
 template <int NW>
 static int launch_lstm(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
-    static bool configured = false;
-    if (!configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)lstm_fused_kernel<NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DGRP_HIP(hipFuncSetAttribute((const void *)lstm_fused_kernel<NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    static std::once_flag configured;
+    static hipError_t cfg_err = hipSuccess;
+    std::call_once(configured, [] {
+        auto set = [](const void *f) { const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) cfg_err = e; };
+        set((const void *)lstm_fused_kernel<NW, 0>);
+        set((const void *)lstm_fused_kernel<NW, 1>);
+    });
+    DGRP_HIP(cfg_err);
     if (p.mode == 0)
         hipLaunchKernelGGL((lstm_fused_kernel<NW, 0>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     else

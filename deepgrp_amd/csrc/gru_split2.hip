@@ -35,6 +35,7 @@
 //     are the compiler's own loads (it waits for them in front of the asm statement);
 //   - the weight loads carry their own s_waitcnt inside the statement that issues them.
 #include "gru_shared.h"
+#include <mutex>
 #include <type_traits>
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -368,11 +369,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 template <int MODE, bool ONERCP>
 int launch_split2(const gru_params &p, int64_t groups, int half_bytes, hipStream_t stream)
 {
-    static bool configured = false;
-    if (!configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)gru_split2_kernel<MODE, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    static std::once_flag configured;        // (records run on a pool of host threads: an unsynchronised flag was a data race)
+    static hipError_t cfg_err = hipSuccess;
+    std::call_once(configured, [] { cfg_err = hipFuncSetAttribute((const void *)gru_split2_kernel<MODE, ONERCP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    DGRP_HIP(cfg_err);
 #ifdef DGRP_STAMP
     if (const char *dump = getenv("DGRP_STAMP_DUMP")) {
         gru_params q = p;

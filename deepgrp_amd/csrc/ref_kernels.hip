@@ -8,6 +8,7 @@
 //                    coalesced from L2 (k-major rows), outputs h_t for every step  -> seq [nw][2][T][u], last [nw][2][u]
 //   ref_head_kernel  one workgroup per window: Average, [additive attention], Dense, Softmax -> probs [nw][T][C]
 #include "dgrp_model.h"
+#include <mutex>
 
 namespace {
 
@@ -22,17 +23,17 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 #endif
 constexpr int RP = DGRP_REF_RP;
 
-template <int CELL>
+// NSL = unit slots per thread: thread j owns units j, j + 256, ... (one slot up to 256 units -- the yardstick of the fused kernels --,
+// more for the models beyond the fused kernels' sizes, which run on these kernels: api.hip, "fp32 path")
+template <int CELL, int NSL>
 __global__ void __launch_bounds__(256) ref_rnn_kernel(const uint8_t *__restrict__ idx, int64_t s, int64_t w0, int64_t npairs,
                                                       int T, int u, const float *__restrict__ kernel,
                                                       const float *__restrict__ rec, const float *__restrict__ bias,
                                                       float *__restrict__ seq, float *__restrict__ last)
 {
     constexpr int G = CELL ? 4 : 3;
-    __shared__ float sh[256 * RP];                           // h_{t-1}[k][pair]
+    extern __shared__ float sh[];                            // h_{t-1}[k][pair], 256 NSL x RP floats
     const int64_t p0 = (int64_t)blockIdx.x * RP;
-    const int j = threadIdx.x;
-    const bool own = j < u;
     const int gu = G * u;
     const uint8_t *x[RP];
     bool live[RP];
@@ -42,30 +43,35 @@ __global__ void __launch_bounds__(256) ref_rnn_kernel(const uint8_t *__restrict_
         const int64_t pr = live[p] ? p0 + p : p0;
         x[p] = idx + (w0 + (pr >> 1)) * s;
     }
-    float h[RP], c[RP];
+    float h[NSL][RP], c[NSL][RP];
 #pragma unroll
-    for (int p = 0; p < RP; ++p) { h[p] = 0.0f; c[p] = 0.0f; }
-    for (int i = j; i < 256 * RP; i += blockDim.x) sh[i] = 0.0f;
+    for (int sl = 0; sl < NSL; ++sl)
+#pragma unroll
+        for (int p = 0; p < RP; ++p) { h[sl][p] = 0.0f; c[sl][p] = 0.0f; }
+    for (int i = threadIdx.x; i < 256 * NSL * RP; i += blockDim.x) sh[i] = 0.0f;
     __syncthreads();
-    float bx[G], bh[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        bx[g] = own ? bias[g * u + j] : 0.0f;
-        bh[g] = (own && CELL == 0) ? bias[gu + g * u + j] : 0.0f;
-    }
     for (int t = 0; t < T; ++t) {
-        float ax[G][RP], ah[G][RP];
-        if (own) {
+        int base[RP];
 #pragma unroll
-            for (int p = 0; p < RP; ++p) {
-                // deepgrp/model.py:266-279: the second pass reads the window backwards through the complement table
-                const int dir = (int)((p0 + p) & 1);
-                int b = dir ? x[p][T - 1 - t] : x[p][t];
-                if (dir) b = b < 4 ? 3 - b : 4;
+        for (int p = 0; p < RP; ++p) {
+            // deepgrp/model.py:266-279: the second pass reads the window backwards through the complement table
+            const int dir = (int)((p0 + p) & 1);
+            int b = dir ? x[p][T - 1 - t] : x[p][t];
+            if (dir) b = b < 4 ? 3 - b : 4;
+            base[p] = b;
+        }
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    ax[g][p] = kernel[(size_t)b * gu + g * u + j] + bx[g];
-                    ah[g][p] = bh[g];
+        for (int sl = 0; sl < NSL; ++sl) {
+            const int j = threadIdx.x + 256 * sl;
+            if (j >= u) continue;
+            float ax[G][RP], ah[G][RP];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float bx = bias[g * u + j], bh = CELL == 0 ? bias[gu + g * u + j] : 0.0f;
+#pragma unroll
+                for (int p = 0; p < RP; ++p) {
+                    ax[g][p] = kernel[(size_t)base[p] * gu + g * u + j] + bx;
+                    ah[g][p] = bh;
                 }
             }
             for (int k = 0; k < u; ++k) {
@@ -86,30 +92,37 @@ __global__ void __launch_bounds__(256) ref_rnn_kernel(const uint8_t *__restrict_
                     const float z = sigmoidf_(ax[0][p] + ah[0][p]);
                     const float r = sigmoidf_(ax[1][p] + ah[1][p]);
                     const float hh = tanhf(ax[2][p] + r * ah[2][p]);
-                    h[p] = z * h[p] + (1.0f - z) * hh;
+                    h[sl][p] = z * h[sl][p] + (1.0f - z) * hh;
                 } else {
                     const float ig = sigmoidf_(ax[0][p] + ah[0][p]);
                     const float fg = sigmoidf_(ax[1][p] + ah[1][p]);
                     const float og = sigmoidf_(ax[G - 1][p] + ah[G - 1][p]);
-                    c[p] = fg * c[p] + ig * tanhf(ax[2][p] + ah[2][p]);
-                    h[p] = og * tanhf(c[p]);
+                    c[sl][p] = fg * c[sl][p] + ig * tanhf(ax[2][p] + ah[2][p]);
+                    h[sl][p] = og * tanhf(c[sl][p]);
                 }
             }
         }
         __syncthreads();                                     // every thread has read h_{t-1}
-        if (own) {
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) {
+            const int j = threadIdx.x + 256 * sl;
+            if (j >= u) continue;
 #pragma unroll
             for (int p = 0; p < RP; ++p) {
-                sh[j * RP + p] = h[p];
-                if (live[p]) seq[((size_t)(p0 + p) * T + t) * u + j] = h[p];
+                sh[j * RP + p] = h[sl][p];
+                if (live[p]) seq[((size_t)(p0 + p) * T + t) * u + j] = h[sl][p];
             }
         }
         __syncthreads();
     }
-    if (own)
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+        const int j = threadIdx.x + 256 * sl;
+        if (j >= u) continue;
 #pragma unroll
         for (int p = 0; p < RP; ++p)
-            if (live[p]) last[(size_t)(p0 + p) * u + j] = h[p];
+            if (live[p]) last[(size_t)(p0 + p) * u + j] = h[sl][p];
+    }
 }
 
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float *scratch)
@@ -131,14 +144,16 @@ __global__ void __launch_bounds__(256) ref_head_kernel(int T, int u, int C, int 
                                                        const float *__restrict__ ffk, const float *__restrict__ ffb,
                                                        float *__restrict__ e, float *__restrict__ probs)
 {
-    __shared__ float q[256], ctx[256], ctxlogit[16], scratch[4];
+    extern __shared__ float qc[];                            // q[u], ctx[u]
+    __shared__ float ctxlogit[16], scratch[4];
+    float *const q = qc, *const ctx = qc + u;
     const int64_t w = blockIdx.x;
     const float *fwd = seq + (size_t)(w * 2) * T * u, *rev = fwd + (size_t)T * u;
     const int tid = threadIdx.x;
     for (int c = tid; c < 16; c += 256) ctxlogit[c] = 0.0f;
     if (attention) {
         // AdditiveAttention with the averaged final states as the single query (deepgrp/model.py:309-319)
-        if (tid < u) q[tid] = 0.5f * (last[(size_t)(w * 2) * u + tid] + last[(size_t)(w * 2 + 1) * u + tid]);
+        for (int k = tid; k < u; k += 256) q[k] = 0.5f * (last[(size_t)(w * 2) * u + k] + last[(size_t)(w * 2 + 1) * u + k]);
         __syncthreads();
         float *ew = e + (size_t)w * T;
         float mx = -INFINITY;
@@ -158,11 +173,11 @@ __global__ void __launch_bounds__(256) ref_head_kernel(int T, int u, int C, int 
         }
         den = block_reduce(den, false, scratch);
         __syncthreads();                                     // ew[] complete for every thread
-        if (tid < u) {
+        for (int k = tid; k < u; k += 256) {
             float acc = 0.0f;
             for (int t = 0; t < T; ++t)
-                acc += (ew[t] / den) * 0.5f * (fwd[(size_t)t * u + tid] + rev[(size_t)t * u + tid]);
-            ctx[tid] = acc;
+                acc += (ew[t] / den) * 0.5f * (fwd[(size_t)t * u + k] + rev[(size_t)t * u + k]);
+            ctx[k] = acc;
         }
         __syncthreads();
         if (tid < C) {
@@ -230,13 +245,20 @@ DGRP_EXPORT int dgrp_forward_windows_reference(const dgrp_model *m, const uint8_
     const float *kernel = raw + m->raw_kernel, *rec = raw + m->raw_rec, *bias = raw + m->raw_bias;
     const float *ffk = raw + m->raw_ffk, *ffb = raw + m->raw_ffb, *scale = raw + m->raw_scale;
     const int64_t npairs = 2 * nw;
-    const dim3 grid((unsigned)((npairs + RP - 1) / RP)), block((unsigned)((m->u + 63) / 64 * 64));
-    if (m->cell == 0)
-        hipLaunchKernelGGL(ref_rnn_kernel<0>, grid, block, 0, stream, d_idx, s, w0, npairs, m->T, m->u, kernel, rec, bias, seq, last);
-    else
-        hipLaunchKernelGGL(ref_rnn_kernel<1>, grid, block, 0, stream, d_idx, s, w0, npairs, m->T, m->u, kernel, rec, bias, seq, last);
+    const int nsl = (m->u + 255) / 256;
+    DGRP_REQUIRE(nsl <= 8, "dgrp_forward_windows_reference: units=%d (up to 2048)", m->u);
+    const dim3 grid((unsigned)((npairs + RP - 1) / RP)), block((unsigned)(nsl > 1 ? 256 : (m->u + 63) / 64 * 64));
+    const size_t lds = (size_t)256 * (nsl <= 1 ? 1 : nsl <= 2 ? 2 : nsl <= 4 ? 4 : 8) * RP * sizeof(float);
+#define REF_GO(CELLv, NSLv) do {                                                                                              \
+        static std::once_flag once_; static hipError_t err_ = hipSuccess;                                                     \
+        std::call_once(once_, [] { err_ = hipFuncSetAttribute((const void *)ref_rnn_kernel<CELLv, NSLv>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }); \
+        DGRP_HIP(err_);                                                                                                        \
+        hipLaunchKernelGGL((ref_rnn_kernel<CELLv, NSLv>), grid, block, lds, stream, d_idx, s, w0, npairs, m->T, m->u, kernel, rec, bias, seq, last); } while (0)
+    if (m->cell == 0) { if (nsl <= 1) REF_GO(0, 1); else if (nsl <= 2) REF_GO(0, 2); else if (nsl <= 4) REF_GO(0, 4); else REF_GO(0, 8); }
+    else { if (nsl <= 1) REF_GO(1, 1); else if (nsl <= 2) REF_GO(1, 2); else if (nsl <= 4) REF_GO(1, 4); else REF_GO(1, 8); }
+#undef REF_GO
     DGRP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ref_head_kernel, dim3((unsigned)nw), dim3(256), 0, stream, m->T, m->u, m->C, m->attention, seq, last,
+    hipLaunchKernelGGL(ref_head_kernel, dim3((unsigned)nw), dim3(256), (size_t)2 * m->u * sizeof(float), stream, m->T, m->u, m->C, m->attention, seq, last,
                        scale, ffk, ffb, e, d_probs);
     DGRP_LAUNCH_CHECK();
     return DGRP_OK;

@@ -14,6 +14,7 @@
 // GRU: two-reciprocal gate chain of gru_shared.h (beyond 128 units the one-reciprocal form is not offered);
 // LSTM: c = f c + i tanh(z_c), h = o tanh(c) exactly as lstm_fused_kernel evaluates them (accumulators in the exp2 domain).
 #include "gru_shared.h"
+#include <mutex>
 
 template <int CELL, int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) rnn_split_stream_kernel(const gru_params pin)
@@ -161,14 +162,15 @@ __global__ void __launch_bounds__(64 * NW, 2) rnn_split_stream_kernel(const gru_
 template <int CELL, int NW>
 static int launch_stream(const gru_params &p, int64_t groups, size_t lds, hipStream_t stream)
 {
-    static bool configured = false;
-    if (!configured) {
-        DGRP_HIP(hipFuncSetAttribute((const void *)rnn_split_stream_kernel<CELL, NW, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DGRP_HIP(hipFuncSetAttribute((const void *)rnn_split_stream_kernel<CELL, NW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (CELL == 0)
-            DGRP_HIP(hipFuncSetAttribute((const void *)rnn_split_stream_kernel<CELL, NW, CELL ? 1 : 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    static std::once_flag configured;
+    static hipError_t cfg_err = hipSuccess;
+    std::call_once(configured, [] {
+        auto set = [](const void *f) { const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) cfg_err = e; };
+        set((const void *)rnn_split_stream_kernel<CELL, NW, 0>);
+        set((const void *)rnn_split_stream_kernel<CELL, NW, 1>);
+        if (CELL == 0) set((const void *)rnn_split_stream_kernel<CELL, NW, CELL ? 1 : 2>);
+    });
+    DGRP_HIP(cfg_err);
     if (p.mode == 0)
         hipLaunchKernelGGL((rnn_split_stream_kernel<CELL, NW, 0>), dim3((unsigned)groups), dim3(64 * NW), lds, stream, p);
     else if (p.mode == 1 || CELL == 1)
@@ -179,7 +181,7 @@ static int launch_stream(const gru_params &p, int64_t groups, size_t lds, hipStr
     return DGRP_OK;
 }
 
-// GRU with 5..8 waves (129-256 units), LSTM with 1..4 waves (up to 128 units)
+// GRU with 5..8 waves (129-256 units), LSTM with 1..8 waves (up to 256 units)
 int dgrp_stream_launch(const gru_params &p, int cell, int NW, int64_t groups, size_t lds, hipStream_t stream)
 {
     if (cell == 0) {
@@ -196,6 +198,10 @@ int dgrp_stream_launch(const gru_params &p, int cell, int NW, int64_t groups, si
         case 2: return launch_stream<1, 2>(p, groups, lds, stream);
         case 3: return launch_stream<1, 3>(p, groups, lds, stream);
         case 4: return launch_stream<1, 4>(p, groups, lds, stream);
+        case 5: return launch_stream<1, 5>(p, groups, lds, stream);
+        case 6: return launch_stream<1, 6>(p, groups, lds, stream);
+        case 7: return launch_stream<1, 7>(p, groups, lds, stream);
+        case 8: return launch_stream<1, 8>(p, groups, lds, stream);
         default: break;
         }
     }

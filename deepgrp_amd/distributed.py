@@ -171,17 +171,17 @@ def _forward_rows(pipe, d_idx: torch.Tensor, w0: int, nw: int, lo: int, hi: int)
     out = torch.zeros((max(hi - lo, 1), C_), dtype=torch.float32, device=d_idx.device)
     if nw <= 0:
         return out
-    m.set_precision(1 if getattr(pipe, "split", False) else 0)
+    h = pipe.handle                                # the pipeline's own view of the model (its precision level)
     base = out.data_ptr() - lo * C_ * 4
-    chunk = max(16, min(int(getattr(pipe, "chunk_windows", 1 << 20)), L.dgrp_forward_window_chunk(m.handle)))
+    chunk = max(16, min(int(getattr(pipe, "chunk_windows", 1 << 20)), L.dgrp_forward_window_chunk(h)))
     work = None
     w = w0
     while w < w0 + nw:
         k = min(chunk, w0 + nw - w)
-        wb = L.dgrp_forward_workspace_bytes(m.handle, k)
+        wb = L.dgrp_forward_workspace_bytes(h, k)
         if work is None or work.numel() < wb:
             work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
-        check(L.dgrp_forward_merge(m.handle, d_idx.data_ptr(), n, pipe.step, pipe.batch, w, k, base, work.data_ptr(), work.numel(),
+        check(L.dgrp_forward_merge(h, d_idx.data_ptr(), n, pipe.step, pipe.batch, w, k, base, work.data_ptr(), work.numel(),
                                    stream_ptr()), "dgrp_forward_merge")
         w += k
     return out

@@ -71,6 +71,7 @@ class DeviceModel:
                                                _np_ptr(self.recurrent_kernel), _np_ptr(self.bias), _np_ptr(self.ff_kernel),
                                                _np_ptr(self.ff_bias)), "dgrp_model_create_lstm")
             self.handle = h
+            self._warn_fp32_path()
             return
         if rnn != "GRU":
             raise ValueError(f"unknown rnn {rnn!r}")
@@ -86,6 +87,16 @@ class DeviceModel:
                                       _np_ptr(self.scale) if self.attention else None, _np_ptr(self.ff_kernel),
                                       _np_ptr(self.ff_bias)), "dgrp_model_create")
         self.handle = h
+        self._warn_fp32_path()
+
+    def _warn_fp32_path(self) -> None:
+        """More units than any fused kernel takes: the model runs, on the plain-fp32 kernels (the reference takes any `units`,
+        deepgrp/model.py:117,219-229) -- said once, loudly, because it is 10-20x slower than a model of 256 units."""
+        self.fp32_only = bool(lib().dgrp_model_flags(self.handle) & 4)
+        if self.fp32_only:
+            import warnings
+            warnings.warn(f"{self.rnn} with {self.units} units is beyond the fused kernels (256 units): every forward pass runs on the "
+                          f"plain-fp32 kernels, tens of Mbp/s", RuntimeWarning, stacklevel=3)
 
     input_shape = property(lambda self: (None, self.vecsize, 5))
     output_shape = property(lambda self: (None, self.vecsize, self.classes))
@@ -124,8 +135,15 @@ class DeviceModel:
         return True
 
     def set_precision(self, level: int) -> None:
-        """dgrp_model_set_precision: 0 = fp16 operands (default), 1 = split operands, for every later call."""
+        """dgrp_model_set_precision: 0 = fp16 operands (`--fast`), 1 = split operands (the default of every model), for every later
+        call on THIS handle.  Pipelines do not call it: each holds a view of its own (`view`)."""
         check(lib().dgrp_model_set_precision(self.handle, int(level)), "dgrp_model_set_precision")
+
+    def view(self, level: int) -> C.c_void_p:
+        """dgrp_model_view: a second handle on the same device buffers with its own precision level (release: dgrp_model_destroy)."""
+        v = C.c_void_p()
+        check(lib().dgrp_model_view(self.handle, int(level), C.byref(v)), "dgrp_model_view")
+        return v
 
     def close(self):
         if getattr(self, "handle", None):
@@ -243,7 +261,7 @@ class ContigPipeline:
 
     def __init__(self, model: DeviceModel, step_size: int = 50, batch_size: int = 256, min_mss_len: int = 50,
                  xdrop_len: int = 50, use_mss: bool = True, chunk_windows: int = 1 << 20, precise: bool = False,
-                 fast: bool = False):
+                 fast: bool = False, fp32: bool = False):
         self.model = model
         self.step = int(step_size)
         self.batch = int(batch_size)
@@ -251,23 +269,40 @@ class ContigPipeline:
         self.xdrop_len = int(xdrop_len)
         self.use_mss = bool(use_mss)
         self.chunk_windows = int(chunk_windows)
-        # Which forward kernel runs ("accuracy"):
-        #   default  the split-operand fused kernel where it exists (GRU, <= 128 units: every base within ~1e-6 of fp32,
-        #            ~1e-5 with attention), the fp16-operand fused kernel for the other models;
-        #   fast     the fp16-operand fused kernel everywhere (2.5x faster; 1e-3 on all but ill-conditioned windows);
-        #   precise  like default, but attention models and models without a split kernel go through the plain-fp32
-        #            kernels (30 Mbp/s).
+        # Which forward kernels run:
+        #   default  split operands -- every model has such a fused kernel (class probabilities within 1e-5 of a float64
+        #            evaluation in the tests, attention models included: their avg[t] crosses to the second kernel as float32);
+        #   fast     fp16 operands (2-2.5x faster; 1e-3 on all but ill-conditioned windows);
+        #   precise  accepted and equal to the default since round 2 made the default fp32-grade for every model (it used to send
+        #            attention models through the 30 Mbp/s plain-fp32 kernels);
+        #   fp32     the plain-fp32 kernels of ref_kernels.hip with the reference's own batch loop -- the yardstick, for tools.
         if precise and fast:
             raise ValueError("precise and fast exclude each other")
         self.precise, self.fast = bool(precise), bool(fast)
-        can_split = bool(getattr(model, "supports_split", False))
-        # attention models keep avg[t] as fp16 between their two kernels even with the split pre-pass (1e-5-level, not
-        # amplified by the recurrence): `precise` sends them through the fp32 kernels all the same
-        self.fp32 = self.precise and (not can_split or bool(getattr(model, "attention", False)))
-        self.split = not self.fast and can_split and not self.fp32
+        self.fp32 = bool(fp32)
+        self.split = not self.fast and not self.fp32
         self.event_log = None        # bench.py: list collecting (start, end, windows) per GRU launch
+        self._view = None            # this pipeline's own handle on the model (dgrp_model_view): its precision level is never
+                                     # changed, so pipelines of different levels can share a model on a pool of host threads
         if self.step < 1 or self.batch < 1:
             raise ValueError("step_size and batch_size must be >= 1")
+
+    @property
+    def handle(self):
+        if self._view is None:
+            self._view = self.model.view(1 if self.split else 0)
+        return self._view
+
+    def close(self) -> None:
+        if self._view is not None:
+            lib().dgrp_model_destroy(self._view)
+            self._view = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # A3-A6
     def merged(self, d_idx: torch.Tensor) -> torch.Tensor:
@@ -275,7 +310,6 @@ class ContigPipeline:
         n = d_idx.numel()
         out = torch.zeros((n, m.classes), dtype=torch.float32, device=d_idx.device)      # np.zeros, prediction.py:103
         nwin = L.dgrp_window_count(n, m.vecsize, self.step)
-        m.set_precision(1 if self.split else 0)
         if self.fp32:
             # the reference's own loop (prediction.py:104-110): batches of B windows, batch i lands at row i * b * step
             # (b = size of THAT batch); the forward pass runs for several batches at a time
@@ -295,18 +329,18 @@ class ContigPipeline:
                     i += 1
                 w0 += nw
             return out
-        chunk = max(16, min(self.chunk_windows, L.dgrp_forward_window_chunk(m.handle)))     # attention: the avg[t] spill bounds a launch
+        chunk = max(16, min(self.chunk_windows, L.dgrp_forward_window_chunk(self.handle)))     # attention: the avg[t] spill bounds a launch
         work = None
         w0 = 0
         while w0 < nwin:
             nw = min(chunk, nwin - w0)
-            wb = L.dgrp_forward_workspace_bytes(m.handle, nw)
+            wb = L.dgrp_forward_workspace_bytes(self.handle, nw)
             if work is None or work.numel() < wb:
                 work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
             if self.event_log is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            check(L.dgrp_forward_merge(m.handle, _ptr(d_idx), n, self.step, self.batch, w0, nw, _ptr(out),
+            check(L.dgrp_forward_merge(self.handle, _ptr(d_idx), n, self.step, self.batch, w0, nw, _ptr(out),
                                        _ptr(work), work.numel(), stream_ptr()), "dgrp_forward_merge")
             if self.event_log is not None:
                 ev1.record()
@@ -372,19 +406,18 @@ class ContigPipeline:
         (the staged merged -> labels -> segments path is kept for callers that time or inspect the stages)."""
         if self.event_log is not None or self.fp32:
             return self.segments(self.labels(self.merged(d_idx)), startpos, contig)
-        self.model.set_precision(1 if self.split else 0)
         L = lib()
         n = d_idx.numel()
         if n == 0:
             return np.zeros(0, SEGMENT_DTYPE)
         dev = d_idx.device
-        wb = L.dgrp_record_workspace_bytes(self.model.handle, n, self.step, int(self.use_mss))
+        wb = L.dgrp_record_workspace_bytes(self.handle, n, self.step, int(self.use_mss))
         work = torch.empty(wb, dtype=torch.uint8, device=dev)
         cap = max(1024, n // 64)
         count = C.c_int64(0)
         while True:
             rec = torch.empty(cap * SEGMENT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            check(L.dgrp_predict_record(self.model.handle, _ptr(d_idx), n, self.step, self.batch, self.min_mss_len,
+            check(L.dgrp_predict_record(self.handle, _ptr(d_idx), n, self.step, self.batch, self.min_mss_len,
                                         self.xdrop_len, int(self.use_mss), int(startpos), int(contig), _ptr(rec), cap,
                                         C.byref(count), _ptr(work), wb, stream_ptr()), "dgrp_predict_record")
             if count.value <= cap:
@@ -395,7 +428,7 @@ class ContigPipeline:
 
     def batchable(self) -> bool:
         """dgrp_predict_batch covers every model on the MSS path (the -m softmax is normalised per record)."""
-        return self.use_mss and self.event_log is None and not self.fp32
+        return self.use_mss and self.event_log is None and not self.fp32 and not getattr(self.model, "fp32_only", False)
 
     def run_batch(self, d_base: torch.Tensor, offsets, lengths, startposes, contigs) -> np.ndarray:
         """Segment records of MANY short records whose class indices lie in one device buffer (record r: `lengths[r]`
@@ -404,13 +437,12 @@ class ContigPipeline:
         nrec = len(lengths)
         if nrec == 0:
             return np.zeros(0, SEGMENT_DTYPE)
-        self.model.set_precision(1 if self.split else 0)
         off = np.ascontiguousarray(offsets, np.int64)
         ln = np.ascontiguousarray(lengths, np.int64)
         sp = np.ascontiguousarray(startposes, np.int64)
         cg = np.ascontiguousarray(contigs, np.int32)
         dev = d_base.device
-        wb = L.dgrp_batch_workspace_bytes(self.model.handle, nrec, ln.ctypes.data, self.step)
+        wb = L.dgrp_batch_workspace_bytes(self.handle, nrec, ln.ctypes.data, self.step)
         if wb <= 0:
             raise ValueError("run_batch: every record of a batch needs at least one base")
         work = torch.empty(wb, dtype=torch.uint8, device=dev)
@@ -418,7 +450,7 @@ class ContigPipeline:
         count = C.c_int64(0)
         while True:
             rec = torch.empty(cap * SEGMENT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-            check(L.dgrp_predict_batch(self.model.handle, _ptr(d_base), nrec, off.ctypes.data, ln.ctypes.data, sp.ctypes.data,
+            check(L.dgrp_predict_batch(self.handle, _ptr(d_base), nrec, off.ctypes.data, ln.ctypes.data, sp.ctypes.data,
                                        cg.ctypes.data, self.step, self.batch, self.min_mss_len, self.xdrop_len, _ptr(rec), cap,
                                        C.byref(count), _ptr(work), wb, stream_ptr()), "dgrp_predict_batch")
             if count.value <= cap:

@@ -108,12 +108,17 @@ int dgrp_windows_onehot(const uint8_t *d_idx, int64_t n, int64_t T, int64_t s, i
  * (deepgrp/__main__.py:264-270; layer graph deepgrp/model.py:293-336).  Host float32 arrays in
  * Keras layout, gate columns z|r|h:  kernel [5,3u], recurrent [u,3u], bias [2,3u],
  * scale [u] or NULL (no attention), ff_kernel [(attention?2u:u), C], ff_bias [C].
- * Packs them into MFMA fragment order and uploads (synchronous). */
+ * Packs them into MFMA fragment order and uploads (synchronous).
+ * Sizes: 1 <= u <= 2048, 2 <= C <= 16 (the reference's classes are len(repeats_to_search) + 1 = 5; its post-processing histograms
+ * are laid out for up to 16 here), 1 <= T <= 65535.  Up to 256 units the fused kernels run; beyond, the model is created on the
+ * "fp32 path" (dgrp_model_flags bit 2): every forward call goes through the plain-fp32 kernels of ref_kernels.hip, tens of Mbp/s --
+ * the reference takes any `units` (deepgrp/model.py:117,219-229), so a large model is slow here, not refused. */
 int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *h_kernel,
                       const float *h_recurrent, const float *h_bias, const float *h_scale,
                       const float *h_ff_kernel, const float *h_ff_bias);
 /* rnn = "LSTM" variant (deepgrp/model.py:219-223, no attention): kernel [5,4u], recurrent [u,4u],
- * bias [4u], gate columns i|f|c|o; ff_kernel [u, C], ff_bias [C].  u <= 128. */
+ * bias [4u], gate columns i|f|c|o; ff_kernel [u, C], ff_bias [C].  Up to 128 units both kernel sets exist; 129-256 units run the
+ * streamed split-operand kernel at either precision level; beyond 256 units the fp32 path, as above. */
 int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, const float *h_kernel,
                            const float *h_recurrent, const float *h_bias, const float *h_ff_kernel,
                            const float *h_ff_bias);
@@ -122,17 +127,25 @@ int dgrp_model_dims(const dgrp_model *m, int *T, int *u, int *C, int *attention)
 /* Which kernel variant the constructor chose (diagnostic; results are the same within tolerance):
  * bit 0 = GRU blend with one reciprocal per (row, unit) -- only when the weights' absolute column sums
  * prove (1 + 2^az)(1 + 2^ag) finite in float32; otherwise (or with DGRP_GRU_SAFE=1 in the environment at
- * construction) the two-reciprocal form.  Negative on a NULL model. */
+ * construction) the two-reciprocal form; bit 1 = precision level 1 (below); bit 2 = the model runs on the fp32 path (more units
+ * than the fused kernels take).  Negative on a NULL model. */
 int dgrp_model_flags(const dgrp_model *m);
-/* (addition) Precision of the recurrent contraction for every later call on this model:
- * 1 = split operands, the DEFAULT wherever such a kernel exists (GRU up to 128 units): weights and hidden state enter the matrix
- * cores as fp16 hi+lo pairs, three MFMA passes, fp32-grade pre-activations (with attention it is the recurrent pre-pass that runs
- * split; avg[t] crosses to the second kernel as fp16); 0 = fp16 MFMA operands, the default of the other models (LSTM, GRU beyond
- * 128 units), ~2x faster, class probabilities within 1e-3 of fp32 except on ill-conditioned windows.  DGRP_EINVAL for level 1 on a
- * model without a split kernel.  dgrp_model_flags bit 1 reports the level.  The level is a property of the HANDLE, read by every
- * call at launch time: host threads may share a handle as long as none of them changes the level while another has calls in
- * flight (set it once, before sharing; the package's pool of record threads uses one level per pipeline). */
+/* (addition) Precision of the recurrent contraction for every later call on this handle:
+ * 1 = split operands, the DEFAULT of every model: weights and hidden state enter the matrix cores as fp16 hi+lo pairs, three MFMA
+ * passes, fp32-grade pre-activations -- class probabilities within 1e-5 of a float64 evaluation in the package's tests (GRU up to 64
+ * units: gru_wave_kernel; 97-128 units: gru_split2_kernel; other GRU sizes up to 128 units: gru_split_kernel; GRU with 129-256 units
+ * and the LSTM cell up to 256 units: rnn_split_stream_kernel).  With attention the recurrent pre-pass runs split and avg[t] crosses to
+ * the second kernel as FLOAT32 (fp16 at level 0).
+ * 0 = fp16 MFMA operands (`predict --fast`): 2-2.5x faster, class probabilities within 1e-3 of fp32 except on ill-conditioned windows
+ * (measure with `python -m deepgrp_amd verify`).  The LSTM cell beyond 128 units and models on the fp32 path (dgrp_model_flags bit
+ * 2) have one kernel set and accept either level.  DGRP_EINVAL for any other level.  dgrp_model_flags bit 1 reports the level.
+ * The level is a property of the HANDLE, read by every call at launch time: do not change it on a handle other host threads are
+ * using -- give each user its own view (dgrp_model_view) instead. */
 int dgrp_model_set_precision(dgrp_model *m, int level);
+/* (addition) A second handle on the same device-resident model with its own precision level: shares every buffer of `m` (which must
+ * outlive it), costs nothing, is released with dgrp_model_destroy.  The package's pipelines hold one view each, so that pipelines of
+ * different levels can run records on a pool of host threads without touching each other's setting. */
+int dgrp_model_view(const dgrp_model *m, int level, dgrp_model **out);
 
 /* ---- A4: model.predict_on_batch (deepgrp/prediction.py:106)
  * Bytes of scratch HBM dgrp_forward_* needs for `nw` windows in one call. */

@@ -37,13 +37,13 @@ CASES = [
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 0, 32, 5, 0, P, P, P, P, P, None), "window size"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 70000, 32, 5, 0, P, P, P, P, P, None), "window size"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 0, 5, 0, P, P, P, P, P, None), "units"),
-    ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 257, 5, 0, P, P, P, P, P, None), "units"),
+    ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 2049, 5, 0, P, P, P, P, P, None), "units"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 1, 0, P, P, P, P, P, None), "classes"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 17, 0, P, P, P, P, P, None), "classes"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 5, 0, P, None, P, None, P, P), "NULL tensor"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 5, 1, P, P, P, None, P, P), "NULL tensor"),   # attention without a scale
     ("dgrp_model_create_lstm", lambda: (None, 200, 32, 5, P, P, P, P, P), "NULL out"),
-    ("dgrp_model_create_lstm", lambda: (C.pointer(C.c_void_p()), 200, 129, 5, P, P, P, P, P), "units"),
+    ("dgrp_model_create_lstm", lambda: (C.pointer(C.c_void_p()), 200, 2049, 5, P, P, P, P, P), "units"),
     ("dgrp_model_create_lstm", lambda: (C.pointer(C.c_void_p()), 200, 32, 5, P, P, None, P, P), "NULL tensor"),
     ("dgrp_model_dims", lambda: (None, None, None, None, None), "NULL model"),
     ("dgrp_model_flags", lambda: (None,), "NULL model"),

@@ -130,7 +130,7 @@ def test_model_create_rejects_bad_shapes_on_device(L, orc):
     k, r, b, fk, fb = [a.ctypes.data for a in arrs]
     ptrs = [k, r, b, None, fk, fb]                                           # no attention scale
     h = C.c_void_p(123)
-    assert L.dgrp_model_create(C.byref(h), 40, 300, 5, 0, *ptrs) == EINVAL and h.value is None
+    assert L.dgrp_model_create(C.byref(h), 40, 3000, 5, 0, *ptrs) == EINVAL and h.value is None         # (up to 2048 units: the fp32 path)
     h = C.c_void_p(123)
     assert L.dgrp_model_create(C.byref(h), 40, 32, 5, 1, *ptrs) == EINVAL and h.value is None
     assert L.dgrp_model_create(C.byref(h), 40, 32, 5, 0, *ptrs) == 0 and h.value

@@ -166,20 +166,23 @@ def test_cli_verify(tmp_path):
     assert float(lines[0][3]) < 1e-5 and float(lines[1][3]) < 1e-3
 
 
-# --------------------------------------------------------------------------------- precise mode (predict --precise)
+# --------------------------------------------------------------------------------- the plain-fp32 forward as a pipeline (fp32=True)
 @pytest.mark.parametrize("u,T,attention,use_mss,B", [(64, 100, False, True, 256), (24, 60, True, True, 37), (32, 100, False, False, 100)])
-def test_precise_pipeline_vs_oracle(dev, orc, u, T, attention, use_mss, B):
-    """The whole path with the fp32 forward: merged probabilities within 2e-5 of the float64 statement driven by the
-    reference's own batch loop (partial last batch included), rows identical to the post-processing of
-    exactly those probabilities."""
+def test_fp32_pipeline_vs_oracle(dev, orc, u, T, attention, use_mss, B):
+    """The whole path with the fp32 forward (ContigPipeline(fp32=True): the yardstick kernels with the reference's own batch loop):
+    merged probabilities within 2e-5 of the float64 statement driven by that loop (partial last batch included), rows
+    identical to the post-processing of exactly those probabilities.  `precise=True` (the command line's --precise) is the DEFAULT
+    pipeline since every model has an fp32-grade fused kernel: same kernels, same rows."""
     from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence
     rng = np.random.default_rng(u + B)
     w = orc.Weights.random(u, 5, T, attention, seed=3, gain=2.0)
     dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
     body = "".join(rng.choice(list("ACGT"), size=20011))
     seq = "NNNN" + body[:7000] + "N" * 300 + body[7000:] + "NN"
-    pipe = ContigPipeline(dm, 50, B, 50, 50, use_mss, precise=True)
-    assert pipe.split == (not attention) and pipe.fp32 == attention and pipe.batchable() == (use_mss and not attention)
+    pipe = ContigPipeline(dm, 50, B, 50, 50, use_mss, fp32=True)
+    assert not pipe.split and pipe.fp32 and not pipe.batchable()
+    prec, dflt = ContigPipeline(dm, 50, B, 50, 50, use_mss, precise=True), ContigPipeline(dm, 50, B, 50, 50, use_mss)
+    assert prec.split and not prec.fp32 and prec.batchable() == use_mss
     st, d_idx = upload_sequence(seq.encode())
     idx = d_idx.cpu().numpy()
     nwin = orc.window_count(idx.size, T, 50)
@@ -188,6 +191,8 @@ def test_precise_pipeline_vs_oracle(dev, orc, u, T, attention, use_mss, B):
     want_merged = orc.predict_merged(idx, lambda a, b: orc.nn_forward(idx, w, 50, a, b, np.float64), T, 5, 50, B)
     assert np.abs(merged - want_merged).max() < 2e-5
     rows = pipe.run(seq, contig=1)
+    np.testing.assert_array_equal(prec.run(seq, contig=1), dflt.run(seq, contig=1))
+    assert np.abs(prec.merged(d_idx).cpu().numpy() - want_merged).max() < 1e-5         # the default is fp32-grade itself
     probs = dm.forward_windows_reference(d_idx, 50, 0, nwin).cpu().numpy()
     want = orc.predict_contig(seq, lambda _idx: (lambda a, b: probs[a:a + b]), T, 5, 50, B, 50, 50, use_mss)
     np.testing.assert_array_equal(np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3), want)

@@ -172,23 +172,20 @@ def test_reverse_complement_layer():
 
 
 def test_pipeline_kernel_selection_table():
-    """Which forward kernel a pipeline uses: split operands by default where the model has them, fp16
-    operands with fast=True or where it has not, plain fp32 with precise=True for attention models and models without
-    a split kernel."""
+    """Which forward kernels a pipeline uses: split operands by default for EVERY model (also with precise=True, which
+    used to mean the plain-fp32 kernels for attention models), fp16 operands with fast=True, the plain-fp32 yardstick only when asked
+    for by name; a model on the fp32 path (more units than the fused kernels take) does not batch."""
     from types import SimpleNamespace
     from deepgrp_amd.pipeline import ContigPipeline
     gru = SimpleNamespace(supports_split=True, attention=False)
     att = SimpleNamespace(supports_split=True, attention=True)
-    big = SimpleNamespace(supports_split=False, attention=False)          # LSTM, or more than 128 units
-    table = {  # (model, precise, fast) -> (split, fp32)
-        (0, False, False): (True, False), (0, True, False): (True, False), (0, False, True): (False, False),
-        (1, False, False): (True, False), (1, True, False): (False, True), (1, False, True): (False, False),
-        (2, False, False): (False, False), (2, True, False): (False, True), (2, False, True): (False, False),
-    }
-    for (mi, precise, fast), (split, fp32) in table.items():
-        pipe = ContigPipeline((gru, att, big)[mi], 50, 256, 50, 50, True, precise=precise, fast=fast)
-        assert (pipe.split, pipe.fp32) == (split, fp32), (mi, precise, fast)
-        assert pipe.batchable() == (not fp32)
+    big = SimpleNamespace(supports_split=True, attention=False, fp32_only=True)          # more than 256 units
+    for model in (gru, att, big):
+        for kw, want in (({}, (True, False)), ({"precise": True}, (True, False)), ({"fast": True}, (False, False)),
+                         ({"fp32": True}, (False, True))):
+            pipe = ContigPipeline(model, 50, 256, 50, 50, True, **kw)
+            assert (pipe.split, pipe.fp32) == want, (model, kw)
+            assert pipe.batchable() == (not want[1] and model is not big)
     with pytest.raises(ValueError, match="exclude"):
         ContigPipeline(gru, precise=True, fast=True)
     with pytest.raises(ValueError):

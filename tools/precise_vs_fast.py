@@ -16,10 +16,7 @@ what = sys.argv[3] if len(sys.argv) > 3 else "fp16-vs-split"          # or split
 def make(kind):
     if kind == "fp16":
         return ContigPipeline(m, fast=True)
-    pipe = ContigPipeline(m, precise=True)
-    if kind == "fp32":
-        pipe.split, pipe.fp32 = False, True        # force the plain-fp32 kernels instead of the split-operand fused kernel
-    return pipe
+    return ContigPipeline(m, fp32=(kind == "fp32"))     # "split" = the default; "fp32" = the plain-fp32 kernels
 a_kind, b_kind = what.split("-vs-")
 fast, precise = make(a_kind), make(b_kind)
 print(f"A = {a_kind} ({'fused, fp16 operands' if a_kind == 'fp16' else 'fused, split operands'}), "

@@ -7,7 +7,7 @@ per = {}
 for f in glob.glob(os.path.join(d, "p*", "**", "*counter_collection.csv"), recursive=True):
     rows = list(csv.DictReader(open(f)))
     for r in rows:
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         ent = per.setdefault(name, {})
         ent.setdefault(r["Counter_Name"], []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), int(r["Grid_Size"])))
 for name, ent in sorted(per.items(), key=lambda kv: -sum(v for _d, v, _g in kv[1].get("SQ_WAVE_CYCLES", [(0, 0, 0)]))):
