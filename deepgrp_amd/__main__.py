@@ -180,7 +180,8 @@ class CommandLineParser:
                   else "fused, split operands (fp32-grade)" if pipe.split else "fused, fp16 operands")
         outstream = None
         if rank == 0:
-            outstream = sys.stdout if args.output == "-" else open(args.output, "w")
+            # (headers are carried as bytes through surrogateescape: a Latin-1 header must reach the file as the bytes it was)
+            outstream = sys.stdout if args.output == "-" else open(args.output, "w", errors="surrogateescape")
 
         def records_of(filename):
             if filename.endswith(".npz") and os.path.isfile(filename):
@@ -217,10 +218,24 @@ class CommandLineParser:
 
         try:
             if world == 1:
+                import time
                 for filename in args.FASTA:
                     _LOG.info("Processing %s", filename)
-                    for kind, key, rows in runner.results(records_of(filename)):
-                        outstream.write(rows_text_batch(filename, key, rows) if kind == "batch" else rows_text(filename, key, rows))
+                    t_file, bases = time.perf_counter(), 0
+                    if _LOG.isEnabledFor(logging.DEBUG):
+                        # -vv: record by record through the staged form of the same path, a device sync and a clock around every
+                        # stage (the reference logs a debug line around each stage of _predict, deepgrp/__main__.py:69-79)
+                        for header, rec in records_of(filename):
+                            rows, n = CommandLineParser._predict_staged(pipe, header, rec)
+                            bases += n
+                            outstream.write(rows_text(filename, header, rows))
+                    else:
+                        for kind, key, rows in runner.results(CommandLineParser._counted(records_of(filename), lambda n: None)):
+                            outstream.write(rows_text_batch(filename, key, rows) if kind == "batch" else rows_text(filename, key, rows))
+                        bases = CommandLineParser._last_count
+                    dt = time.perf_counter() - t_file
+                    _LOG.info("%s: %d bases in %.3f s (%.1f Mbp/s; ingest, upload, forward, MSS, segments and TSV text)", filename, bases, dt,
+                              bases / max(dt, 1e-9) / 1e6)
             else:
                 from .distributed import run_split
                 if getattr(args, "split_contigs", False):
@@ -251,6 +266,61 @@ class CommandLineParser:
             # interpreter shutdown)
             if rank == 0 and args.output != "-":
                 outstream.close()
+
+    _last_count = 0
+
+    @staticmethod
+    def _counted(records, _cb):
+        """Pass (header, record) pairs through, adding up the bases they hold (for the per-file rate of -v)."""
+        from .fasta import DeviceRecord
+        CommandLineParser._last_count = 0
+        for header, rec in records:
+            CommandLineParser._last_count += max(rec.length, 0) + max(rec.startpos, 0) if isinstance(rec, DeviceRecord) else len(rec)
+            yield header, rec
+
+    @staticmethod
+    def _predict_staged(pipe, header, rec):
+        """One record through encode -> forward + merge -> scores / MSS / vote (or softmax) -> segments, each stage between device
+        syncs, with the reference's debug lines (deepgrp/__main__.py:69-79) carrying the stage's milliseconds.  -> (rows, bases)"""
+        import time
+
+        import torch
+
+        from .fasta import DeviceRecord
+        from .pipeline import SEGMENT_DTYPE, upload_sequence
+
+        def lap(t):
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t) * 1e3
+        t = time.perf_counter()
+        _LOG.debug("One hot encoding sequence.")
+        if isinstance(rec, DeviceRecord):
+            if rec.length < 0:
+                raise ValueError("negative dimensions are not allowed")
+            startpos, d_idx = rec.startpos, rec.d_idx
+        else:
+            startpos, d_idx = upload_sequence(rec.encode("utf-8"))
+        n = int(d_idx.numel())
+        ms_enc = lap(t)
+        if n == 0:
+            return np.zeros(0, SEGMENT_DTYPE), 0
+        t = time.perf_counter()
+        _LOG.debug("Start prediction.")
+        merged = pipe.merged(d_idx)
+        ms_fwd = lap(t)
+        _LOG.debug("Finish prediction.")
+        t = time.perf_counter()
+        if pipe.use_mss:
+            _LOG.debug("Applying MSS.")
+        labels = pipe.labels(merged)
+        ms_post = lap(t)
+        t = time.perf_counter()
+        rows = pipe.segments(labels, startpos)
+        ms_seg = lap(t)
+        _LOG.debug("%s: %d bases; encode %.2f ms, forward + merge %.2f ms (%.1f Mbp/s), %s %.2f ms, segments + read-back %.2f ms, %d rows",
+                   header, n, ms_enc, ms_fwd, n / max(ms_fwd, 1e-6) / 1e3, "scores + MSS + vote" if pipe.use_mss else "softmax", ms_post,
+                   ms_seg, len(rows))
+        return rows, n
 
     @staticmethod
     def _predict_sharded(args, runner, records_of, outstream) -> None:

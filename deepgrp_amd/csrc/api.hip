@@ -46,13 +46,19 @@ static thread_local std::vector<timed_launch> g_timed;
 dgrp_timer_scope::dgrp_timer_scope(hipStream_t s, int64_t nw) : stream(s), windows(nw), start(nullptr), on(g_timer_on)
 {
     if (!on) return;
-    if (hipEventCreate(&start) != hipSuccess || hipEventRecord(start, stream) != hipSuccess) on = false;
+    if (hipEventCreate(&start) != hipSuccess) { on = false; start = nullptr; return; }
+    if (hipEventRecord(start, stream) != hipSuccess) { on = false; (void)hipEventDestroy(start); start = nullptr; }
 }
 dgrp_timer_scope::~dgrp_timer_scope()
 {
     if (!on) return;
     hipEvent_t stop = nullptr;
-    if (hipEventCreate(&stop) == hipSuccess && hipEventRecord(stop, stream) == hipSuccess) g_timed.push_back({ start, stop, windows });
+    if (hipEventCreate(&stop) == hipSuccess && hipEventRecord(stop, stream) == hipSuccess) {
+        g_timed.push_back({ start, stop, windows });
+        return;
+    }
+    if (stop) (void)hipEventDestroy(stop);                    // no pair, no measurement: neither event may leak
+    (void)hipEventDestroy(start);
 }
 
 static void timer_clear()

@@ -325,6 +325,52 @@ def test_cli_many_records_batched_path(orc, tmp_path):
     assert want.count("\n") > 100
 
 
+def test_cli_verbose_stage_times_and_fp32_path_model(orc, tmp_path, caplog):
+    """-vv: the staged path with the reference's debug lines (deepgrp/__main__.py:69-79) and the milliseconds of every stage,
+    -v: bases / seconds / Mbp/s per file; the TSV is the one the default run writes.  And a model beyond the fused kernels' sizes
+    (288 GRU units: the fp32 path) through the command line: a warning, not a refusal, rows = the oracle's post-processing of
+    the device's probabilities."""
+    import logging
+    import warnings
+    from deepgrp_amd.__main__ import main
+    from deepgrp_amd.pipeline import upload_sequence
+    rng = np.random.default_rng(12)
+    fasta = tmp_path / "two.fa"
+    seqs = ["".join(rng.choice(list("ACGT"), size=n)) for n in (5000, 900)]
+    fasta.write_text("".join(f">rec{i}\n{s}\n" for i, s in enumerate(seqs)))
+    model_file = os.path.join(GOLDEN, "model_u8_T20.h5")
+    plain, verbose = tmp_path / "plain.tsv", tmp_path / "verbose.tsv"
+    main(["-s", "4", "-b", "7", "predict", model_file, str(fasta), "--output", str(plain)])
+    with caplog.at_level(logging.DEBUG, logger="deepgrp_amd.__main__"):
+        main(["-vv", "-s", "4", "-b", "7", "predict", model_file, str(fasta), "--output", str(verbose)])
+    text = caplog.text
+    assert verbose.read_text() == plain.read_text() and plain.read_text().count("\n") > 5
+    for needle in ("One hot encoding sequence.", "Start prediction.", "Finish prediction.", "Applying MSS.", "forward + merge",
+                   "scores + MSS + vote", "segments + read-back", "Mbp/s"):
+        assert needle in text, needle
+    assert text.count("forward + merge") == 2                                     # one stage line per record
+    logging.getLogger("deepgrp_amd.__main__").setLevel(logging.WARNING)
+    # ---- 288 units
+    w = orc.Weights.random(288, 5, 30, False, seed=4, gain=1.0)
+    big = str(tmp_path / "big.hdf5")
+    dgmodel.save_keras_hdf5(big, w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, None, vecsize=30)
+    out = tmp_path / "big.tsv"
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        main(["-s", "5", "-b", "7", "-l", "4", "-x", "6", "predict", big, str(fasta), "--output", str(out)])
+        model = dgmodel.load_model(big)
+    assert any("beyond the fused kernels" in str(x.message) for x in seen) and model.fp32_only
+    want = []
+    for i, sq in enumerate(seqs):
+        st, d_idx = upload_sequence(sq.encode())
+        nwin = orc.window_count(d_idx.numel(), 30, 5)
+        probs = model.forward_windows(d_idx, 5, 0, nwin).cpu().numpy()
+        assert np.abs(probs - orc.nn_forward(d_idx.cpu().numpy(), w, 5, 0, nwin, np.float64)).max() < 5e-5
+        rows = orc.predict_contig(sq, lambda _i: (lambda a, b: probs[a:a + b]), 30, 5, 5, 7, 4, 6, True)
+        want += [f"{fasta}\trec{i}\t{a}\t{b}\t{c}\n" for a, b, c in rows]
+    assert out.read_text() == "".join(want)
+
+
 def test_cli_with_lstm_model(orc, tmp_path):
     """`deepgrp predict` with an rnn="LSTM" model file: rows equal the oracle's post-processing of the
     GPU probabilities, probabilities within 1e-3 of the float64 LSTM statement."""

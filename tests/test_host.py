@@ -476,7 +476,9 @@ def test_fast_fasta_reader_equals_reference_loop(tmp_path):
              ">a\r\n" + wrap(seq(200), 60, "\r\n") + "\r\n>b\r\nAC\r\n", ">a\n" + wrap(seq(100)) + "\n\n>b\nAC\n",
              ">a\nAC GT\n  >b\nTT\n>c\n\tGG \n", ">a\nACGT", ">a\nACGT\n>\nGG\n>c\nTT\n", ">a\n>b\n>c\nA\n", "",
              ">only header\n", ">a\nAC\rGT\n", ">a\nACGT\n\n", "\n>a\nAC\n", ">a\n\xc3\xa4CGT\n",
-             ">h\rnn", ">h x\rACGT\n>b\nTT\n", ">h\r\nAC\r\n", ">h\r"]
+             ">h\rnn", ">h x\rACGT\n>b\nTT\n", ">h\r\nAC\r\n", ">h\r",
+             # a Latin-1 byte in a header / in a body: not UTF-8, the reference's text-mode open raises UnicodeDecodeError -- and so does this
+             ">a\nACGT\n>h\xe4 x\nACGT\n", ">a\nAC\xe4GT\n"]
     for i, text in enumerate(cases):
         path = tmp_path / f"c{i}.fa"
         path.write_bytes(text.encode("latin-1"))
@@ -494,7 +496,14 @@ def test_fast_fasta_reader_equals_reference_loop(tmp_path):
             with open(path, "r") as fh:
                 yield from read_multi_fasta_lines(fh)
 
-        assert run(lambda: read_multi_fasta_file(str(path))) == run(ref), f"case {i}: {text[:30]!r}"
+        got, want = run(lambda: read_multi_fasta_file(str(path))), run(ref)
+        if want[1] == "UnicodeDecodeError":
+            # text mode decodes a buffer of 8 KiB ahead of the line it hands out, so WHICH records the reference still yields in front
+            # of an undecodable byte depends on its buffering; this reader decodes record by record: the same error, and every record
+            # the reference got out is one of ours, in order
+            assert got[1] == want[1] and got[0][:len(want[0])] == want[0], f"case {i}: {text[:30]!r}"
+            continue
+        assert got == want, f"case {i}: {text[:30]!r}"
 
 
 def test_record_runner_grouping_and_order():
