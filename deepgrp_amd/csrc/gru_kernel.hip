@@ -930,6 +930,12 @@ __global__ void __launch_bounds__(256, (UP <= 64 && sizeof(AT) == 4) ? DGRP_ATT_
     constexpr int PCH = (CM <= 8 && PIPE) ? 8 : 0;           // 64-step chunks of stored logit halves kept in registers (T <= 512)
     att_chunk nxt[DEPTH][CPR];
     auto fetch = [&](att_chunk (&dst)[CPR], const AT *avg, int t0) {
+        if (t0 + 64 <= T) {                                  // a whole tile: one pointer, the chunks at constant offsets of 1 KiB
+            const att_chunk *src = reinterpret_cast<const att_chunk *>(avg + (int64_t)t0 * UP) + lane;
+#pragma unroll
+            for (int j = 0; j < CPR; ++j) dst[j] = src[j * 64];
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < CPR; ++j) {
             // steps behind the window's end read its last row again (their weight below is 0): a predicated load sits in a basic
