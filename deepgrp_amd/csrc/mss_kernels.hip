@@ -497,14 +497,25 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
             double base = cert ? cur : 0.0;
             const double front = cur;                             // the value in front of the chunk
             int p = 0;
-            // ---- (3c) growing-candidate shortcut.  With exactly one candidate c on the stack, a run whose
-            // start lies above c.L and whose end exceeds c.R is absorbed by c (mss.c:68-81: found, merged,
-            // stack empty, "flush", pushed again with R = the run's end, max = R).  If every run that closes in the
-            // chunk does that -- run ends strictly increasing and above c.R, starts above c.L, no x-drop trigger --
-            // the chunk only moves c.R / c.en / max: no serial stack work.  A run may reach into the chunk (it closes
-            // at its first non-positive element, lane 0 included) and one may reach out of it (it stays open).
-            if (nst == 1) {
-                const cand_v c0 = get(0);
+            // ---- (3c) growing-candidate shortcut.  A run whose start lies above the TOP candidate's L and whose end exceeds its R
+            // is absorbed by it (mss.c:68-76: found, merged, popped); the search then goes on from the top's own left neighbour b
+            // (its `pre`: the nearest candidate with a smaller L -- the merged run carries the top's L, so it finds the same one):
+            //   * no such neighbour (one candidate on the stack): "flush", pushed again with R = the run's end, max = R (mss.c:78-81);
+            //   * a neighbour whose R the run's end does NOT exceed: pushed again on top of it with R = the run's end -- the stack as
+            //     it was with a larger top (scores drifting upward under an old high peak: every run does exactly this, and
+            //     run by run it was ~1 us of serial stack work each: 2.5 M runs of normal(+0.3, 1) scores took 2.8 s);
+            //   * a neighbour the run's end exceeds: a second merge -- not handled here.
+            // If every run that closes in the chunk does one of the first two -- run ends strictly increasing and above the top's R,
+            // starts above its L, ends not above the neighbour's R, no x-drop trigger -- the chunk only moves the top's R / en and
+            // max: no serial stack work.  A run may reach into the chunk (it closes at its first non-positive element, lane 0
+            // included) and one may reach out of it (it stays open).
+            if (nst >= 1 && nst <= MSS_LCAP) {
+                const cand_v c0 = get(nst - 1);
+                const int64_t nb = c0.pre;
+                const bool lone = nst == 1;                                        // (then pre = -1)
+                double lim = INFINITY;                                             // the neighbour's R: an end above it merges again
+                if (!lone && nb >= 0) lim = get(nb).R;
+                if (lone || nb >= 0) {
                 const double V = base + pre;
                 const bool edge_close = run_open && !(mpos & 1ull);          // the open run ended with the previous chunk
                 const bool isend = ispos && lane + 1 < nvalid && !((mpos >> (lane + 1)) & 1ull);
@@ -519,12 +530,14 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                 }
                 double before = __shfl_up(rmax, 1);               // run ends strictly before this lane
                 if (lane == 0) before = -INFINITY;
-                const double base_r = edge_close ? cur : c0.R, base_peak = edge_close ? cur : peak;
+                const double base_r = edge_close ? cur : c0.R;
+                // max in front of this lane: one candidate: every run close sets it to the run's end (flush); else the running maximum
+                const double base_peak = edge_close ? (lone ? cur : (cur > peak ? cur : peak)) : peak;
                 const double top_r = before > base_r ? before : base_r;
-                const double peak_i = before > -INFINITY ? before : base_peak;
+                const double peak_i = lone ? (before > -INFINITY ? before : base_peak) : (before > base_peak ? before : base_peak);
                 bool ok = !run_open || c0.L < run_L;                             // the open run's own start (p->L < t.L)
-                if (edge_close) ok = ok && cur > c0.R;
-                if (isend) ok = ok && V > top_r;                                  // seg.a[j].R < t.R
+                if (edge_close) ok = ok && cur > c0.R && !(lim < cur);
+                if (isend) ok = ok && V > top_r && !(lim < V);                    // seg.a[j].R < t.R for the top, not for its neighbour
                 if (isstart) ok = ok && (c0.L < vprev);                          // p->L < t.L
                 if (lane < nvalid && !ispos && xdrop > 0.0 && V + xdrop < peak_i) ok = false;   // x-drop would fire
                 if (__all(ok)) {
@@ -533,11 +546,11 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                         const int last = mend ? 63 - __builtin_clzll(mend) : -1;  // last positive lane of the last closed run
                         const double newR = mend ? lane_value(V, last) : cur;
                         if (lane == 0) {
-                            sLR[0] = make_double2(c0.L, newR);
-                            sIdx[0] = make_int4(c0.st, (int32_t)(pos + last + 1), -1, 0);
+                            sLR[nst - 1] = make_double2(c0.L, newR);
+                            sIdx[nst - 1] = make_int4(c0.st, (int32_t)(pos + last + 1), (int32_t)nb, 0);
                         }
                         __threadfence_block();
-                        peak = newR;
+                        peak = lone ? newR : (newR > peak ? newR : peak);
                     }
                     if ((mpos >> (nvalid - 1)) & 1ull) {
                         // a run reaches out of the chunk: it starts behind the last non-positive lane (none: it reached in as well)
@@ -554,6 +567,7 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                     cur = lane_value(V, nvalid - 1);
                     pos += nvalid;
                     continue;
+                }
                 }
             }
             while (p < nvalid) {

@@ -11,6 +11,11 @@
 // gates in pack order).  At 256 units the matrix pipe is the bound (288 MFMAs per wave-step, two waves per SIMD: ~80 % busy), not the
 // stream: keeping fragments resident or a deeper ring changes nothing -- about 0.4 x the speed of the fp16-operand
 // kernel of the same model, which issues a third of the MFMAs.  Correctness first: no staging of vector work into MFMA gaps.
+// (r03, SQ counters at 256 units: waves 54 % of their time in s_waitcnt, matrix pipe ~50 % busy, 768 KB of fragments per CU and step
+// through a vector-memory path of 64 B per clock = 12 k cycles next to 9.2 k cycles of MFMAs: the CU's L2 -> register path is what it
+// waits for.  U_hi of r and of the candidate resident in AGPRs -- a third less to stream -- does not fit this shape: two waves per SIMD
+// leave 256 registers each, 128 resident + 80 of accumulators and state spill 180 registers at 8 waves; it needs four waves of 64
+// units with the 512-register budget: DESIGN.md 6.)
 // GRU: two-reciprocal gate chain of gru_shared.h (beyond 128 units the one-reciprocal form is not offered);
 // LSTM: c = f c + i tanh(z_c), h = o tanh(c) exactly as lstm_fused_kernel evaluates them (accumulators in the exp2 domain).
 #include "gru_shared.h"
