@@ -470,6 +470,23 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
         // 129-256 units: the streamed split-operand kernel (rnn_stream.hip) is the default, the fp16-operand kernel the --fast mode
         static const float gs3[3] = { -1.4426950408889634f, -1.4426950408889634f, 2.8853900817779268f };
         CREATE_HIP(upload_stream(m, rec, 3, gs3));
+        {
+            // gru_stream64_kernel's input-projection table (rnn_stream.hip): [5 bases][4 kinds r, g (recurrent bias only), z, x][UP units]
+            // fp32, exp2 domain, both biases folded (the two-reciprocal gate chain: no "+1" in the z rows)
+            const int UPm = m->UP;
+            std::vector<float> xt((size_t)5 * 4 * UPm, 0.0f);
+            const double cs = -1.4426950408889634, ch = 2.8853900817779268;
+            for (int b = 0; b < 5; ++b)
+                for (int unit = 0; unit < u; ++unit) {
+                    float *row = &xt[(size_t)b * 4 * UPm];
+                    row[0 * UPm + unit] = (float)(cs * ((double)kernel[(size_t)b * u3 + u + unit] + (double)bias[u + unit] + (double)bias[u3 + u + unit]));
+                    row[1 * UPm + unit] = (float)(ch * (double)bias[u3 + 2 * u + unit]);
+                    row[2 * UPm + unit] = (float)(cs * ((double)kernel[(size_t)b * u3 + unit] + (double)bias[unit] + (double)bias[u3 + unit]));
+                    row[3 * UPm + unit] = (float)(ch * ((double)kernel[(size_t)b * u3 + 2 * u + unit] + (double)bias[2 * u + unit]));
+                }
+            CREATE_HIP(hipMalloc((void **)&m->d_xtab, xt.size() * 4));
+            CREATE_HIP(hipMemcpy(m->d_xtab, xt.data(), xt.size() * 4, hipMemcpyHostToDevice));
+        }
         const char *pe = getenv("DGRP_GRU_PRECISION");
         m->precision = !(pe && pe[0] == '0') ? 1 : 0;
     }

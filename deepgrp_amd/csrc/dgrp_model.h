@@ -63,6 +63,9 @@ int dgrp_wave_carve(int NU, gru_params &p, int mode, int64_t s, int64_t budget);
 int dgrp_wave_table_bytes(int NU);
 int dgrp_wave_launch(const gru_params &p, int NU, int64_t groups, int wave_bytes, bool onercp, hipStream_t stream);
 int dgrp_spill_row(const dgrp_model *m);   // row length of the avg[t] spill (gru_kernel.hip)
+// rnn_stream.hip: GRU with 129-256 units on waves of 64 units with resident hi fragments (NW = 32-unit slices of the model)
+size_t dgrp_stream64_carve(int NW, gru_params &p, int mode, int64_t s, int64_t budget);
+int dgrp_stream64_launch(const gru_params &p, int NW, int64_t groups, size_t lds, hipStream_t stream);
 // batched records (mode 0): see gru_kernel.hip
 int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, const void *d_recs, const int64_t *d_wg_first,
                           int64_t nrec, int64_t total_groups, int mode, float *d_out, void *d_avg, hipStream_t stream);

@@ -1374,6 +1374,12 @@ int dgrp_gru_launch(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_
     const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, tile_budget(m, split));
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T,
                  gru_lds_seq(p.Tp));
+    if (split && m->d_stream && m->cell == 0 && m->d_xtab && !getenv("DGRP_STREAM_PLAIN")) {
+        // GRU, 129-256 units: waves of 64 units, resident hi fragments (rnn_stream.hip); one workgroup per CU
+        const size_t lds64 = dgrp_stream64_carve(m->NW, p, mode, s, 158 * 1024);
+        if (lds64 <= 160 * 1024) return dgrp_stream64_launch(p, m->NW, groups, lds64, stream);
+        (void)gru_tile_carve(m, p, mode, s, split, 8, tile_budget(m, split));          // (window too long for that carve: the all-streamed kernel)
+    }
     if (split && m->d_stream) return dgrp_stream_launch(p, m->cell, m->NW, groups, lds, stream);
     if (split) {
         switch (m->NW) {
@@ -1453,6 +1459,11 @@ int dgrp_gru_launch_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t s, 
     const size_t lds = gru_tile_carve(m, p, mode, s, split, 8, tile_budget(m, split));
     DGRP_REQUIRE(lds <= 160 * 1024, "window size %d: the workgroup's staged sequences (%d bytes of LDS) do not fit 160 KiB", m->T,
                  gru_lds_seq(p.Tp));
+    if (split && m->d_stream && m->cell == 0 && m->d_xtab && !getenv("DGRP_STREAM_PLAIN")) {
+        const size_t lds64 = dgrp_stream64_carve(m->NW, p, mode, s, 158 * 1024);
+        if (lds64 <= 160 * 1024) return dgrp_stream64_launch(p, m->NW, total_groups, lds64, stream);
+        (void)gru_tile_carve(m, p, mode, s, split, 8, tile_budget(m, split));
+    }
     if (split && m->d_stream) return dgrp_stream_launch(p, m->cell, m->NW, total_groups, lds, stream);
     if (split) {
         switch (m->NW) {

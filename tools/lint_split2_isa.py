@@ -210,6 +210,9 @@ def main():
     ap.add_argument("asm")
     ap.add_argument("--kernel", default="gru_split2_kernel")
     ap.add_argument("--fix", metavar="OUT", help="write a copy with the missing wait states inserted, and audit that copy")
+    ap.add_argument("--max-acc-copies", type=int, default=ACC_COPIES_ALLOWED,
+                    help="v_accvgpr_read / _write tolerated per kernel (a kernel that fills its 256 architectural VGPRs lets the allocator park "
+                         "values in free AGPRs: a few dozen per step are noise; hundreds are the weights being copied, the round-1 pathology)")
     a = ap.parse_args()
     if a.fix:
         before = sum(len(audit(body)) for _n, body in kernels(a.asm, a.kernel))
@@ -229,9 +232,9 @@ def main():
         body_n = sum(1 for x in body if not x.label)
         acc = [x for x in body if x.mn.startswith("v_accvgpr")]
         if acc:                                                    # a handful = the allocator parking a value in a free AGPR; the pathology is hundreds
-            bad = len(acc) > ACC_COPIES_ALLOWED
+            bad = len(acc) > a.max_acc_copies
             total += 1 if bad else 0
-            print(f"{name}: {len(acc)} v_accvgpr copies{' (more than ' + str(ACC_COPIES_ALLOWED) + ')' if bad else ' (tolerated)'}, first: line {acc[0].line}: {acc[0].text}")
+            print(f"{name}: {len(acc)} v_accvgpr copies{' (more than ' + str(a.max_acc_copies) + ')' if bad else ' (tolerated)'}, first: line {acc[0].line}: {acc[0].text}")
         print(f"{name}: {body_n} instructions, {nm} MFMAs, {len(hits)} hazard(s)")
         for kind, first, second, states in hits[:12]:
             need = STATES_VALU_TO_MFMA if kind == "A" else STATES_MFMA_TO_USE
