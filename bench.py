@@ -53,7 +53,7 @@ def parse_args():
                     help="trained: deepgrp_amd/data/synthetic_gru128.npz (fitted to the planted repeats, genome-like output); "
                          "random: Keras initialisers scaled by --gain (stationary noise, the MSS worst case)")
     ap.add_argument("--gain", type=float, default=3.0, help="weight scale of the random model")
-    ap.add_argument("--cpu-sample-bp", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-bp", type=int, default=2_000_000, help="bases of the all-threads CPU sample (10-30 s of CPU work on a 128-thread host)")
     ap.add_argument("--fast", action="store_true", help="time the fp16-operand GRU kernel instead of the default split-operand one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the timed steps: no stages / e2e / other-mode / accuracy legs")
@@ -94,7 +94,7 @@ def cpu_baseline(weights, sample_bp: int):
 
     dt, nrows = run(sample_bp, threads)
     # the reference's default is --threads 1 (deepgrp/__main__.py:133-139): the same path on one thread, a sample of a few seconds
-    one_bp = 60_000
+    one_bp = min(300_000, max(60_000, sample_bp // 6))
     dt1, _ = run(one_bp, 1)
     return {"value": round(sample_bp / dt / 1e6, 5), "unit": "Mbp/s", "cores": int(threads), "kind": "port",
             "sample": f"{sample_bp} bp synthetic contig, full path (oracle/dgrp_oracle.c, float32, OpenMP over windows), "
