@@ -260,10 +260,9 @@ __device__ __forceinline__ void flush_image(const gru_params &p, const wg_ctx &c
 
 // attention pre-pass of the split-operand kernels: avg[t] of this wave's 32 units for window (lane & 15), summed from the
 // hi and lo halves of both strands (the second kernel's operand)
-__device__ __forceinline__ void split_avg_store(const gru_params &p, int64_t wg_w, int tt, int UP, int wave, half8 a0, half8 a1,
-                                                half8 l0, half8 l1)
+__device__ __forceinline__ void split_avg_store_lane(const gru_params &p, int64_t wg_w, int tt, int UP, int wave, int lane, half8 a0, half8 a1,
+                                                     half8 l0, half8 l1)
 {
-    const int lane = threadIdx.x & 63;
     const int64_t at = ((wg_w + (lane & 15) - p.w0 + p.avgw) * (int64_t)p.T + tt) * UP + 32 * wave + 8 * (lane >> 4);
     if (p.avg_f32) {
         // fp32 spill: avg = ((f_hi + f_lo) + (r_hi + r_lo)) / 2 in float, so that the attention kernel sees what the recurrence computed
@@ -297,6 +296,11 @@ __device__ __forceinline__ void split_avg_store(const gru_params &p, int64_t wg_
     const _Float16 hf = (_Float16)0.5f;
     const half8 av = (a0 * hf + a1 * hf) + (l0 + l1) * hf;
     *reinterpret_cast<half8 *>(reinterpret_cast<_Float16 *>(p.avg) + at) = av;
+}
+__device__ __forceinline__ void split_avg_store(const gru_params &p, int64_t wg_w, int tt, int UP, int wave, half8 a0, half8 a1,
+                                                half8 l0, half8 l1)
+{
+    split_avg_store_lane(p, wg_w, tt, UP, wave, threadIdx.x & 63, a0, a1, l0, l1);
 }
 
 // Gate math of ONE (row, unit) of the split-operand kernels as a chain of single operations, written once so that the

@@ -11,11 +11,8 @@
 // gates in pack order).  At 256 units the matrix pipe is the bound (288 MFMAs per wave-step, two waves per SIMD: ~80 % busy), not the
 // stream: keeping fragments resident or a deeper ring changes nothing -- about 0.4 x the speed of the fp16-operand
 // kernel of the same model, which issues a third of the MFMAs.  Correctness first: no staging of vector work into MFMA gaps.
-// (r03, SQ counters at 256 units: waves 54 % of their time in s_waitcnt, matrix pipe ~50 % busy, 768 KB of fragments per CU and step
-// through a vector-memory path of 64 B per clock = 12 k cycles next to 9.2 k cycles of MFMAs: the CU's L2 -> register path is what it
-// waits for.  U_hi of r and of the candidate resident in AGPRs -- a third less to stream -- does not fit this shape: two waves per SIMD
-// leave 256 registers each, 128 resident + 80 of accumulators and state spill 180 registers at 8 waves; it needs four waves of 64
-// units with the 512-register budget: DESIGN.md 6.)
+// (r03: the GRU with 129-256 units moved to gru_stream64_kernel below -- waves of 64 units with the 512-register budget and a third of
+// the fragments resident; this kernel now serves the LSTM cell only.)
 // GRU: two-reciprocal gate chain of gru_shared.h (beyond 128 units the one-reciprocal form is not offered);
 // LSTM: c = f c + i tanh(z_c), h = o tanh(c) exactly as lstm_fused_kernel evaluates them (accumulators in the exp2 domain).
 #include "gru_shared.h"
@@ -165,22 +162,41 @@ __global__ void __launch_bounds__(64 * NW, 2) rnn_split_stream_kernel(const gru_
 }
 
 // ---- GRU, 129-256 units: waves of 64 units with the 512-register budget, U_hi of r and of the candidate RESIDENT -----------------
-// What bounds rnn_split_stream_kernel at 256 units is the CU's vector-memory path, not the matrix pipe: every wave re-reads its 96 KB
-// of fragments from L2 every step -- 768 KB per CU and step through a path that moves 64 B per clock: 12 k cycles, next to 9.2 k cycles
-// of MFMAs for the SIMD's two waves (r03 SQ counters: waves 54 % of their time in s_waitcnt, matrix pipe ~50 % busy).  With two waves
-// per SIMD a wave has 256 registers: no room for resident fragments next to 80 registers of accumulators and state.  Here a workgroup
-// is ceil(UP / 64) waves, ONE per SIMD, each owning 64 units (two 32-unit halves) and all 512 registers: the hi fragments of the r and
-// the candidate gate -- a third of all fragments, 16 KS registers, 256 at 256 units -- live in AGPRs (inline-asm MFMAs name them there;
-// loaded once), U_hi of z and the three U_lo stream (512 KB per CU and step instead of 768), one k-step in flight.  The input
-// projection is a table row the accumulators start from (LDS, as in gru_split2_kernel), the candidate's input projection is read from
-// the table when the gate chain needs it.  Same tile, same three passes, same gate chain and rounding as rnn_split_stream_kernel.
-// The stream layout is that kernel's: [32-unit slice v][k-step][hi z, hi r, hi h, lo z, lo r, lo h][64].
+// A workgroup is ceil(UP / 64) waves, ONE per SIMD, each owning 64 units (two 32-unit halves) of a 16-window tile and all 512
+// registers.  What decides the time of a step at this size is (r03 measurements):
+//   * the CU's vector-memory path: tools/ubench/l2_stream.hip -- four waves re-reading an L2-resident buffer with 16-byte loads get
+//     117-135 GB/s per CU (49-56 B per clock), 92 GB/s while the CU's other waves read LDS; L1-resident data is no faster.  Streaming
+//     ALL recurrent fragments (768 KB per tile-step at 256 units) therefore costs 6-8 us per tile-step whatever the ring depth -- more
+//     than the step's 288 MFMAs (4.4 us).  Hence: U_hi of r and of the candidate live in AGPRs (16 KS registers, 256 at 256 units;
+//     inline-asm MFMAs name them there; loaded once); U_hi of z and the three U_lo stream (512 KB) through a ring of D blocks that
+//     runs on across the time steps, every slot requested again right behind its last MFMA, from a uniform base + one lane offset
+//     in the GLOBAL address space (a laundered generic pointer made them FLAT loads, which count on both wait counters: every
+//     k-step then waited for every load in flight).
+//   * the phases of a step following one another (MFMAs 9.2 k cycles, gate math 4.5 k, waiting): the two 32-unit halves of a wave are
+//     therefore worked one after the other -- all k-steps of half 0, then all k-steps of half 1 WITH the gate chains of half 0, link
+//     by link, in the gaps between those MFMAs (pinned with sched_barrier), half 0's new state published meanwhile (ping-pong tiles);
+//     only half 1's gate math is left behind the MFMAs.
+//   (Measured and dropped: two row tiles per workgroup as two wave groups half a step apart, two waves per SIMD with 256 registers
+//   each -- the overlap is there, no-load time 12.4 k cycles per tile-step against 15 k, but nothing can be resident and the stream
+//   alone takes longer than that: 21.8 Mbp/s against 23.1 for this form on the cfg5 shape without attention.  The ring's depth does
+//   not matter (2, 4: the same time) and loads from an L1-resident 6 KB cost what loads from L2 cost; WITHOUT the loads the step is
+//   19 % shorter: what a streamed kilobyte costs is its way into the SIMD's registers, not its latency.)
+// The state of a unit IS its published fp16 pair (h = hi + lo, exact in float, 2^-22 of h away from the float the gate chain
+// produced): nothing but accumulators, ring and the current chain's temporaries lives in VGPRs.  The input projection is a table row
+// the accumulators start from (LDS, as in gru_split2_kernel).  Same three passes and gate chain as rnn_split_stream_kernel; the
+// stream layout is that kernel's: [32-unit slice v][k-step][hi z, hi r, hi h, lo z, lo r, lo h][64].
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define SMFMA_A(acc, Wf, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(Wf), "v"(b))
 #define SMFMA_V(acc, Wf, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(Wf), "v"(b))
 #define SLOAD2A(a, pa, b, pb)                                                                                           \
     asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off\n\ts_waitcnt vmcnt(0)"            \
                  : "=&a"(a), "=&a"(b) : "v"(pa), "v"(pb) : "memory")
+#ifndef DGRP_S64_RING
+#define DGRP_S64_RING 2
+#endif
+#ifndef DGRP_S64_DIAG
+#define DGRP_S64_DIAG 0
+#endif
 
 template <int NW, int MODE>               // NW = 32-unit slices of the model (5..8); waves = (NW + 1) / 2
 __global__ void __launch_bounds__(64 * ((NW + 1) / 2)) __attribute__((amdgpu_waves_per_eu(1, 1))) gru_stream64_kernel(const gru_params pin)
@@ -190,40 +206,50 @@ __global__ void __launch_bounds__(64 * ((NW + 1) / 2)) __attribute__((amdgpu_wav
     constexpr int NW64 = (NW + 1) / 2, UP = 32 * NW, KS = UP / 16, HS = UP + 8, NF = 6, NFRAG = KS * NF;
     constexpr int XT_PITCH = 4 * UP * 4 + 32;                    // table row of one base: 4 kinds x UP units fp32 + 32 B (bank spread)
     constexpr int NT = 64 * NW64;
+    constexpr int TILE = 32 * HS;                                // halves of one hidden tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = p.T, C = p.C;
     const bool two = 2 * wave + 1 < NW;                           // this wave's second 32-unit half exists (odd NW: not in the last wave)
-    const uint4 *st0 = p.stream + (size_t)(2 * wave) * NFRAG * 64 + lane;
-    const uint4 *st1 = p.stream + (size_t)(two ? 2 * wave + 1 : 2 * wave) * NFRAG * 64 + lane;
-    // resident: U_hi of r (slot 1), both halves: 8 KS AGPRs.  Everything else streams through a ring of D k-steps that runs on across
-    // the time steps (the weights do not depend on t: k-step k of step t + 1 is requested while step t is still in its gate phase), so
-    // that no step starts by waiting for its first fragments.
-    constexpr int D = 2;                                          // k-steps in flight; KS is even
-    static_assert(KS % D == 0, "the ring's slot of a k-step must not depend on the time step");
-    u32x4 Wr[KS][2];
+    // the stream of the wave's two slices: uniform bases (scalar registers) + one lane offset for every load
+    const char *const sb0 = reinterpret_cast<const char *>(p.stream + (size_t)(2 * wave) * NFRAG * 64);
+    const char *const sb1 = reinterpret_cast<const char *>(p.stream + (size_t)(two ? 2 * wave + 1 : 2 * wave) * NFRAG * 64);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto frag = [&](const char *b, int f) -> uint4 {
+        return __builtin_bit_cast(uint4, *reinterpret_cast<const u32x4 __attribute__((address_space(1))) *>(
+                                             (const char __attribute__((address_space(1))) *)b + (size_t)lane16 + (size_t)f * 1024));
+    };
+    // resident: U_hi of r (slot 1) and of the candidate (slot 2), both halves
+    u32x4 Wr[KS][2], Wg[KS][2];
+    {
+        const uint4 *r0 = reinterpret_cast<const uint4 *>(sb0) + lane, *r1 = reinterpret_cast<const uint4 *>(sb1) + lane;
 #pragma unroll
-    for (int k = 0; k < KS; ++k) SLOAD2A(Wr[k][0], st0 + (size_t)(k * NF + 1) * 64, Wr[k][1], st1 + (size_t)(k * NF + 1) * 64);
-    // Dense fragments of the wave's two slices (the 32-unit pack of api.hip)
-    half8 Bd_hi[2], Bd_lo[2];
-#pragma unroll
-    for (int uh = 0; uh < 2; ++uh) {
-        const uint4 *mypack = p.pack + (size_t)(uh == 1 && two ? 2 * wave + 1 : 2 * wave) * p.nfrag * 64 + lane;
-        Bd_hi[uh] = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 1) * 64]);
-        Bd_lo[uh] = __builtin_bit_cast(half8, mypack[(size_t)(3 * (KS + 1) + 2) * 64]);
+        for (int k = 0; k < KS; ++k) {
+            SLOAD2A(Wr[k][0], r0 + (size_t)(k * NF + 1) * 64, Wr[k][1], r1 + (size_t)(k * NF + 1) * 64);
+            SLOAD2A(Wg[k][0], r0 + (size_t)(k * NF + 2) * 64, Wg[k][1], r1 + (size_t)(k * NF + 2) * 64);
+        }
     }
-    // the input-projection table: [5 bases][4 kinds r, g (recurrent bias only), z, x][UP units] fp32 -> LDS rows of XT_PITCH bytes
+    // the input-projection table [5 bases][4 kinds r, g (recurrent bias only), z, x][UP units] fp32 -> LDS rows of XT_PITCH bytes, and
+    // behind it the Dense fragments (hi, lo of the wave's two slices; read when a step's logits are due)
     for (int i = tid; i < 5 * 4 * UP; i += NT)
         *reinterpret_cast<float *>(smem + p.xtab_off + (i / (4 * UP)) * XT_PITCH + (i % (4 * UP)) * 4) = p.xtab[i];
-
+    {
+        uint4 *bd = reinterpret_cast<uint4 *>(smem + p.xtab_off + 5 * XT_PITCH) + (size_t)wave * 4 * 64 + lane;
+#pragma unroll
+        for (int uh = 0; uh < 2; ++uh) {
+            const uint4 *mypack = p.pack + (size_t)(uh == 1 && two ? 2 * wave + 1 : 2 * wave) * p.nfrag * 64 + lane;
+            bd[(2 * uh) * 64] = mypack[(size_t)(3 * (KS + 1) + 1) * 64];
+            bd[(2 * uh + 1) * 64] = mypack[(size_t)(3 * (KS + 1) + 2) * 64];
+        }
+    }
+    _Float16 *const hbuf = reinterpret_cast<_Float16 *>(smem);                            // [2][32][HS] hi tiles
     _Float16 *const lbuf = reinterpret_cast<_Float16 *>(smem + p.lo_tile_off);          // [2][32][HS] lo tiles
-    for (int i = tid; i < 32 * HS; i += NT) lbuf[i] = (_Float16)0.0f;
     // carve, staged sequences, placement: wg_setup's job for 64 NW64 threads and a tile of 32 NW units
     wg_ctx ctx;
     {
-        ctx.hbuf = reinterpret_cast<_Float16 *>(smem);
+        ctx.hbuf = hbuf;
         ctx.dpart = reinterpret_cast<float *>(smem + gru_lds_hbuf(UP, 8));
         ctx.seqs = smem + gru_lds_hbuf(UP, 8) + gru_lds_dpart(NW64);
         ctx.row0s = reinterpret_cast<int64_t *>(ctx.seqs + gru_lds_seq(p.Tp));
@@ -235,7 +261,7 @@ __global__ void __launch_bounds__(64 * ((NW + 1) / 2)) __attribute__((amdgpu_wav
             const int wi = i / T, t = i - wi * T;
             ctx.seqs[wi * p.Tp + t] = wi < ctx.nvalid ? p.idx[(ctx.wg_w + wi) * p.s + t] : (uint8_t)4;
         }
-        for (int i = tid; i < 32 * HS; i += NT) ctx.hbuf[i] = (_Float16)0.0f;          // h_{-1} = 0
+        for (int i = tid; i < TILE; i += NT) { hbuf[i] = (_Float16)0.0f; lbuf[i] = (_Float16)0.0f; }          // h_{-1} = 0
         ctx.lo = 0;
         if (MODE == 0) {
             const int64_t a = dgrp_place_row(p.place, ctx.wg_w, p.s), b = dgrp_place_row(p.place, ctx.wg_w + ctx.nvalid - 1, p.s);
@@ -258,12 +284,6 @@ __global__ void __launch_bounds__(64 * ((NW + 1) / 2)) __attribute__((amdgpu_wav
 
     const int r = lane & 31, wi_a = r & 15, dir = r >> 4, khalf = lane >> 5;
     const uint8_t *myseq = ctx.seqs + wi_a * p.Tp;
-    float h[2][16];
-#pragma unroll
-    for (int uh = 0; uh < 2; ++uh)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) h[uh][i] = 0.0f;
-    _Float16 *hcur = ctx.hbuf, *hnxt = ctx.hbuf + 32 * HS, *lcur = lbuf, *lnxt = lbuf + 32 * HS;
     const f32x4 zero4 = { 0, 0, 0, 0 };
     const int cls = lane & 15;
     const float fbias = cls < C ? p.ffb[cls] : 0.0f;
@@ -273,22 +293,29 @@ __global__ void __launch_bounds__(64 * ((NW + 1) / 2)) __attribute__((amdgpu_wav
             finish_register<NW64, MODE>(p, ctx, t, reg, fbias, ctx.rowoff[wi], ctx.row0s[wi]);
         }
     };
+    // this wave's share of a step's logits (and of avg[t] for the attention pass) from the tile columns it has just written (one wave's
+    // LDS operations execute in order).  The lane index is laundered: what is addressed from it here is recomputed every step instead
+    // of living across the MFMA phases.
     auto dense_issue = [&](const _Float16 *hb, const _Float16 *lb, int tt) -> f32x4 {
         f32x4 d = zero4;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int uh = 0; uh < 2; ++uh) {
             if (uh == 1 && !two) break;
-            const int doff = (lane & 15) * HS + 64 * wave + 32 * uh + 8 * (lane >> 4);
+            const uint4 *bdl = reinterpret_cast<const uint4 *>(smem + p.xtab_off + 5 * XT_PITCH) + (size_t)wave * 4 * 64 + ln;
+            const half8 Bd_hi = __builtin_bit_cast(half8, bdl[(2 * uh) * 64]), Bd_lo = __builtin_bit_cast(half8, bdl[(2 * uh + 1) * 64]);
+            const int doff = (ln & 15) * HS + 64 * wave + 32 * uh + 8 * (ln >> 4);
             const half8 a0 = *reinterpret_cast<const half8 *>(hb + doff), a1 = *reinterpret_cast<const half8 *>(hb + doff + 16 * HS);
             const half8 l0 = *reinterpret_cast<const half8 *>(lb + doff), l1 = *reinterpret_cast<const half8 *>(lb + doff + 16 * HS);
-            if (MODE == 2 && (lane & 15) < ctx.nvalid)
-                split_avg_store(p, ctx.wg_w, tt, UP, 2 * wave + uh, a0, a1, l0, l1);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi[uh], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi[uh], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo[uh], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo[uh], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, Bd_hi[uh], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, Bd_hi[uh], d, 0, 0, 0);
+            if (MODE == 2 && (ln & 15) < ctx.nvalid)
+                split_avg_store_lane(p, ctx.wg_w, tt, UP, 2 * wave + uh, ln, a0, a1, l0, l1);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_hi, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_hi, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, Bd_lo, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, Bd_lo, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, Bd_hi, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, Bd_hi, d, 0, 0, 0);
         }
         return d;
     };
@@ -301,18 +328,18 @@ __global__ void __launch_bounds__(64 * ((NW + 1) / 2)) __attribute__((amdgpu_wav
     // table offset of this lane's units: 64 wave + 32 uh + 8 qd + 4 khalf .. + 3
     const unsigned tab_lane = (unsigned)p.xtab_off + (unsigned)(64 * wave + 4 * khalf) * 4;
 
-    uint4 q[D][2][5];
+    // The ring: blocks b = uh KS + k in the order the MFMAs take them (all k-steps of half 0, then of half 1), cyclic across time steps;
+    // per block the four streamed fragments: 0 hi z, 1 lo z, 2 lo r, 3 lo h (stream slots 0, 3, 4, 5).
+    constexpr int D = DGRP_S64_RING, NB = 2 * KS;
+    static_assert(NB % D == 0, "the ring's slot of a block must not depend on the time step");
+    uint4 q[D][4];
 #pragma unroll
-    for (int k = 0; k < D; ++k)
-#pragma unroll
-        for (int uh = 0; uh < 2; ++uh) {
-            const uint4 *src = (uh ? st1 : st0) + (size_t)k * NF * 64;
-            q[k][uh][0] = src[0]; q[k][uh][1] = src[(size_t)3 * 64]; q[k][uh][2] = src[(size_t)4 * 64]; q[k][uh][3] = src[(size_t)5 * 64];
-            q[k][uh][4] = src[(size_t)2 * 64];
-        }
-    // accumulators start as the table rows of the step's base (kinds 0 r, 1 g, 2 z) -- requested at the END of the step before, in front
-    // of its barrier: the table does not depend on the hidden state, and read behind the barrier the 24 LDS reads were latency every
-    // wave of the workgroup waited out together
+    for (int b = 0; b < D; ++b) {
+        const char *sb = b < KS ? sb0 : sb1;
+        const int f0 = (b % KS) * NF;
+        q[b][0] = frag(sb, f0); q[b][1] = frag(sb, f0 + 3); q[b][2] = frag(sb, f0 + 4); q[b][3] = frag(sb, f0 + 5);
+    }
+    // accumulators start as the table rows of the step's base (kinds 0 r, 1 g, 2 z), requested at the end of the step before
     f32x16 ar[2], ag[2], az[2];
     unsigned tab = 0;
     auto acc_start = [&](int tn) {
@@ -330,80 +357,148 @@ __global__ void __launch_bounds__(64 * ((NW + 1) / 2)) __attribute__((amdgpu_wav
             }
     };
     acc_start(0);
+
+    // one block of the MFMA stream: the nine MFMAs of (half UH, k-step k) with the ring's reloads; HOOK(i) = what goes behind MFMA i
+#if DGRP_S64_DIAG == 2
+#define S64_LD(slot, f) do { } while (0)
+#else
+#define S64_LD(slot, f) qk[slot] = frag(nsb, nf0 + (f))
+#endif
+#define S64_BLOCK(UH, HOOK)                                                                                              \
+    {                                                                                                                   \
+        const int b_ = (UH) * KS + k, nb_ = (b_ + D) % NB;                                                              \
+        uint4 (&qk)[4] = q[b_ % D];                                                                                     \
+        const char *nsb = nb_ < KS ? sp0 : sp1;                                                                         \
+        const int nf0 = (nb_ % KS) * NF;                                                                                \
+        const u32x4 zh = __builtin_bit_cast(u32x4, qk[0]), zl = __builtin_bit_cast(u32x4, qk[1]);                         \
+        const u32x4 rl = __builtin_bit_cast(u32x4, qk[2]), gl = __builtin_bit_cast(u32x4, qk[3]);                         \
+        SMFMA_V(az[UH], zh, hf); HOOK(0);                                                                                \
+        SMFMA_A(ar[UH], Wr[k][UH], hf); HOOK(1);                                                                         \
+        SMFMA_V(az[UH], zh, lf); S64_LD(0, 0); HOOK(2);                                                                  \
+        SMFMA_A(ag[UH], Wg[k][UH], hf); HOOK(3);                                                                         \
+        SMFMA_A(ar[UH], Wr[k][UH], lf); HOOK(4);                                                                         \
+        SMFMA_V(az[UH], zl, hf); S64_LD(1, 3); HOOK(5);                                                                  \
+        SMFMA_A(ag[UH], Wg[k][UH], lf); HOOK(6);                                                                         \
+        SMFMA_V(ar[UH], rl, hf); S64_LD(2, 4); HOOK(7);                                                                  \
+        SMFMA_V(ag[UH], gl, hf); S64_LD(3, 5); HOOK(8);                                                                  \
+    }
+#define S64_NOHOOK(i) do { } while (0)
+    // the gate chain of half 0's element e_ (12 links) spread over the nine gaps of a block of half 1
+#define S64_G(op) split_gate_op<false, op>(gt, ar[0][e_], ag[0][e_], az[0][e_], vx[e_ & 3], hp[e_ & 3])
+#define S64_GATEHOOK(i)                                                                                                  \
+    do {                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        if constexpr ((i) == 0) { S64_G(0); S64_G(1); }                                                                 \
+        else if constexpr ((i) == 1) { S64_G(2); }                                                                      \
+        else if constexpr ((i) == 2) { S64_G(3); }                                                                      \
+        else if constexpr ((i) == 3) { S64_G(4); }                                                                      \
+        else if constexpr ((i) == 4) { S64_G(5); }                                                                      \
+        else if constexpr ((i) == 5) { S64_G(6); S64_G(7); }                                                            \
+        else if constexpr ((i) == 6) { S64_G(8); S64_G(9); }                                                            \
+        else if constexpr ((i) == 7) { S64_G(10); }                                                                     \
+        else { S64_G(11); }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    } while (0)
+
+    // state of four units of a row = their published pair, and back
+    auto pair_load = [&](const _Float16 *hrow, const _Float16 *lrow, float (&hp)[4]) {
+        const uint2 ph = *reinterpret_cast<const uint2 *>(hrow), pl = *reinterpret_cast<const uint2 *>(lrow);
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(hp[0]) : "v"(ph.x), "v"(pl.x));
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hp[1]) : "v"(ph.x), "v"(pl.x));
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(hp[2]) : "v"(ph.y), "v"(pl.y));
+        asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(hp[3]) : "v"(ph.y), "v"(pl.y));
+    };
+    auto pair_store = [&](_Float16 *hrow, _Float16 *lrow, const float (&h4)[4]) {
+        uint2 hv, lv;
+        split_hi_lo4(h4, hv, lv);
+        *reinterpret_cast<uint2 *>(hrow) = hv;
+        *reinterpret_cast<uint2 *>(lrow) = lv;
+    };
+
     for (int t = 0; t < T; ++t) {
         const unsigned tab_t = tab;                            // this step's table row (the candidate's input projection is read below)
+        const _Float16 *hcur = hbuf + (t & 1) * TILE, *lcur = lbuf + (t & 1) * TILE;
+        _Float16 *hnxt = hbuf + ((t + 1) & 1) * TILE, *lnxt = lbuf + ((t + 1) & 1) * TILE;
         const _Float16 *arow = hcur + r * HS + 8 * khalf, *lrow = lcur + r * HS + 8 * khalf;
-        // streamed per k-step and half: U_hi of z (slot 0) and the three U_lo (slots 3 z, 4 r, 5 h)
-        // (the stream pointers are laundered every step: left to itself the compiler hoists the fragment addresses of the unrolled
-        // loop out of the time loop and spills 200 registers)
-        const uint4 *sp[2] = { st0, st1 };
-        asm volatile("" : "+v"(sp[0]), "+v"(sp[1]));
-        // the hidden tile's fragments one k-step ahead of their MFMAs (read right in front of them every k-step waited out an LDS latency)
+        // (the stream bases are laundered every step: left alone the compiler hoists a hundred fragment addresses out of the time loop)
+        const char *sp0 = sb0, *sp1 = sb1;
+        asm volatile("" : "+s"(sp0), "+s"(sp1));
+        // own columns of the tiles: row (lane & 31), units 64 wave + 32 uh + 8 qd + 4 khalf .. + 3
+        const int own = (lane & 31) * HS + 64 * wave + 4 * khalf;
+        // ---- half 0: all k-steps ----
         half8 hfn = *reinterpret_cast<const half8 *>(arow), lfn = *reinterpret_cast<const half8 *>(lrow);
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
             const half8 hf = hfn, lf = lfn;
-            if (k + 1 < KS) {
-                hfn = *reinterpret_cast<const half8 *>(arow + 16 * (k + 1));
-                lfn = *reinterpret_cast<const half8 *>(lrow + 16 * (k + 1));
-            }
-#pragma unroll
-            for (int uh = 0; uh < 2; ++uh) {
-                if (uh == 1 && !two) break;
-                // slots of a k-step: 0 hi z, 1 lo z, 2 lo r, 3 lo h, 4 hi h; the fragments of k-step (k + D) mod KS go where these were
-                uint4 (&qk)[5] = q[k % D][uh];
-                const uint4 *nxt = sp[uh] + (size_t)((k + D) % KS) * NF * 64;
-                const u32x4 zh = __builtin_bit_cast(u32x4, qk[0]), zl = __builtin_bit_cast(u32x4, qk[1]);
-                const u32x4 rl = __builtin_bit_cast(u32x4, qk[2]), gl = __builtin_bit_cast(u32x4, qk[3]), gh = __builtin_bit_cast(u32x4, qk[4]);
-                SMFMA_V(az[uh], zh, hf); SMFMA_A(ar[uh], Wr[k][uh], hf); SMFMA_V(ag[uh], gh, hf);
-                SMFMA_V(az[uh], zh, lf); SMFMA_A(ar[uh], Wr[k][uh], lf); SMFMA_V(ag[uh], gh, lf);
-                qk[0] = nxt[0]; qk[4] = nxt[(size_t)2 * 64];
-                SMFMA_V(az[uh], zl, hf); SMFMA_V(ar[uh], rl, hf); SMFMA_V(ag[uh], gl, hf);
-                qk[1] = nxt[(size_t)3 * 64]; qk[2] = nxt[(size_t)4 * 64]; qk[3] = nxt[(size_t)5 * 64];
-            }
+            hfn = *reinterpret_cast<const half8 *>(arow + 16 * ((k + 1) % KS));
+            lfn = *reinterpret_cast<const half8 *>(lrow + 16 * ((k + 1) % KS));
+            S64_BLOCK(0, S64_NOHOOK)
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(az[0]), "+v"(ar[0]), "+v"(ag[0]), "+v"(az[1]), "+v"(ar[1]), "+v"(ag[1]));   // asm MFMA results -> compiler-scheduled readers
-        f32x4 dpl = zero4;
-        if (t > 0) dpl = dense_issue(hcur, lcur, t - 1);
-        if (t > 1) finish_step(t - 2);
-        if (t > 0) dense_store(t - 1, dpl);
-        // pack order of the GRU gates: z, r, h (api.hip); the candidate's input projection (kind 3) from the table, 4 units at a time
+        // ---- half 1: all k-steps, with half 0's gate chains in the gaps (element e of the lane's 16 at k-step e KS / 16) ----
+        {
+            float hp[4], h4[4];
+            f32x4 vx = zero4;
+            split_gate_tmp gt;
 #pragma unroll
-        for (int uh = 0; uh < 2; ++uh) {
-            if (uh == 1 && !two) break;
+            for (int k = 0; k < KS; ++k) {
+                const half8 hf = hfn, lf = lfn;
+                if (k + 1 < KS) {
+                    hfn = *reinterpret_cast<const half8 *>(arow + 16 * (k + 1));
+                    lfn = *reinterpret_cast<const half8 *>(lrow + 16 * (k + 1));
+                }
+                const int e0 = (16 * k + KS - 1) / KS, e1 = (16 * (k + 1) + KS - 1) / KS;            // elements [e0, e1) belong to this k-step
+                if (e0 < e1) {
+                    const int e_ = e0;
+                    if ((e_ & 3) == 0) {
+                        pair_load(hcur + own + 8 * (e_ >> 2), lcur + own + 8 * (e_ >> 2), hp);
+                        vx = ldsf4(tab_t + 3 * UP * 4 + (8 * (e_ >> 2)) * 4);
+                    }
+                    S64_BLOCK(1, S64_GATEHOOK)
+                    h4[e_ & 3] = hp[e_ & 3];
+                    if ((e_ & 3) == 3) pair_store(hnxt + own + 8 * (e_ >> 2), lnxt + own + 8 * (e_ >> 2), h4);
+                } else {
+                    S64_BLOCK(1, S64_NOHOOK)
+                }
+                // (models below 256 units have fewer k-steps than elements: the rest of this k-step's share in one go)
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const f32x4 vx = ldsf4(tab_t + 3 * UP * 4 + (32 * uh + 8 * qd) * 4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    h[uh][4 * qd + i] = split_gate_chain<false>(ar[uh][4 * qd + i], ag[uh][4 * qd + i], az[uh][4 * qd + i], vx[i], h[uh][4 * qd + i]);
-            }
-            // publish h_t as an fp16 pair: hi = fp16(h), lo = fp16(h - hi)
-            _Float16 *wrow = hnxt + (lane & 31) * HS + 64 * wave + 32 * uh + 4 * khalf;
-            _Float16 *wlow = lnxt + (lane & 31) * HS + 64 * wave + 32 * uh + 4 * khalf;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const float h4[4] = { h[uh][4 * qd], h[uh][4 * qd + 1], h[uh][4 * qd + 2], h[uh][4 * qd + 3] };
-                uint2 hv, lv;
-                split_hi_lo4(h4, hv, lv);
-                *reinterpret_cast<uint2 *>(wrow + 8 * qd) = hv;
-                *reinterpret_cast<uint2 *>(wlow + 8 * qd) = lv;
+                for (int e_ = e0 + 1; e_ < e1; ++e_) {
+                    if ((e_ & 3) == 0) {
+                        pair_load(hcur + own + 8 * (e_ >> 2), lcur + own + 8 * (e_ >> 2), hp);
+                        vx = ldsf4(tab_t + 3 * UP * 4 + (8 * (e_ >> 2)) * 4);
+                    }
+                    h4[e_ & 3] = split_gate_chain<false>(ar[0][e_], ag[0][e_], az[0][e_], vx[e_ & 3], hp[e_ & 3]);
+                    if ((e_ & 3) == 3) pair_store(hnxt + own + 8 * (e_ >> 2), lnxt + own + 8 * (e_ >> 2), h4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(az[1]), "+v"(ar[1]), "+v"(ag[1]));   // asm MFMA results -> compiler-scheduled readers
+        // ---- half 1's gate math (all that is left behind the MFMAs) ----
+        if (t > 0) finish_step(t - 1);
+        if (two) {
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                float hp[4], h4[4];
+                pair_load(hcur + own + 32 + 8 * qd, lcur + own + 32 + 8 * qd, hp);
+                const f32x4 vx = ldsf4(tab_t + 3 * UP * 4 + (32 + 8 * qd) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    h4[i] = split_gate_chain<false>(ar[1][4 * qd + i], ag[1][4 * qd + i], az[1][4 * qd + i], vx[i], hp[i]);
+                pair_store(hnxt + own + 32 + 8 * qd, lnxt + own + 32 + 8 * qd, h4);
+            }
+        }
+        dense_store(t, dense_issue(hnxt, lnxt, t));
         if (t + 1 < T) acc_start(t + 1);
         __syncthreads();
-        _Float16 *tmp = hcur; hcur = hnxt; hnxt = tmp;
-        tmp = lcur; lcur = lnxt; lnxt = tmp;
     }
-    {
-        const f32x4 dpl = dense_issue(hcur, lcur, T - 1);
-        if (T > 1) finish_step(T - 2);
-        dense_store(T - 1, dpl);
-        __syncthreads();
-        finish_step(T - 1);
-    }
+    finish_step(T - 1);
     if (MODE == 0 && p.ospan > 0) flush_image<NW64>(p, ctx);
+#undef S64_BLOCK
+#undef S64_GATEHOOK
+#undef S64_NOHOOK
+#undef S64_G
+#undef S64_LD
 }
 
 template <int NW>
@@ -440,12 +535,12 @@ int dgrp_stream64_launch(const gru_params &p, int NW, int64_t groups, size_t lds
     }
 }
 
-// LDS carve: hi tiles, partial logits of (NW + 1) / 2 waves, sequences, placement, image (as much as `budget` allows), lo tiles, table.
-// Sets p.ospan, p.lo_tile_off, p.xtab_off; returns the bytes.
+// LDS carve: hi tiles (ping-pong), partial logits of (NW + 1) / 2 waves, sequences, placement, image (as much as `budget` allows),
+// lo tiles, table, Dense fragments.  Sets p.ospan, p.lo_tile_off, p.xtab_off; returns the bytes.
 size_t dgrp_stream64_carve(int NW, gru_params &p, int mode, int64_t s, int64_t budget)
 {
     const int UP = 32 * NW, NW64 = (NW + 1) / 2;
-    const int tiles = gru_lds_hbuf(UP, 8), xtab = 5 * (4 * UP * 4 + 32);
+    const int tiles = gru_lds_hbuf(UP, 8), xtab = 5 * (4 * UP * 4 + 32) + NW64 * 4 * 1024;
     const int fixed = tiles + gru_lds_dpart(NW64) + gru_lds_seq(p.Tp) + gru_lds_meta();
     p.ospan = 0;
     if (mode == 0) {
