@@ -32,6 +32,22 @@
 // ------------------------------------------------------------------------------------------
 struct mss_cand { int32_t st, en; double L, R; int32_t pre, pad; };   // mss.c:24-28
 
+#define MSS_SUB_MIN 256        // light units of at least this many 64-blocks may split a piece (sizes the dump slots)
+#define MSS_SUBENT_BYTES 80
+// A unit of the SUB-PIECE scan (r03; DESIGN.md 3.3 device 8): a piece, or the part of a piece behind a speculative light edge
+// inside it.  The light walk's converged end states give every such edge its exact entry state, so the stack scan of a long piece
+// (scores drifting upward under old peaks: millions of runs on one stack) runs on all its parts at once, each on a LOCAL stack
+// above an unknown rest; mss_stitch_kernel then replays only the candidates whose search ran off the local stack's bottom.
+struct mss_subent {
+    int64_t start, run;       // first score; first stack/segment slot (= runs that start in front of the unit)
+    double L, peak, run_L;    // entry state: running value, max since the last flush, the open run's start value
+    int64_t run_st;           // the open run's start
+    int32_t open, first;      // a run is open at the start; the unit opens its piece (its stack is the reference's own)
+    int32_t vci, nst;         // compact index of the unit's speculative edge (dump slot 2 vci; a piece's head: 2 vci(next unit) + 1); OUT: its stack's size
+    int32_t reset, pad;       // OUT: an x-drop reset fired (the piece ends with this unit)
+    double Lf;                // entry state: the smallest run start value since the last flush (a closed run at or below it flushes)
+};
+static_assert(sizeof(mss_subent) == 80, "MSS_SUBENT_BYTES");
 #define MSS_LCAP 160          // candidates kept in LDS per wave; deeper ones spill to HBM
 #define MSS_NEG (-1e30)       // NEG_INF, mss.c:33
 #define MSS_QNONE (-4096)
@@ -64,6 +80,9 @@ struct mss_layout {            // carve of the caller's workspace
     int2 *cut_kj;              // [nblk] (stretch, ordinal of the piece in its stretch)
     int64_t *ustart2, *urun2;  // [npieces+1] pieces: start, first stack/segment slot  (npieces <= 2*nblk + 1)
     double *entry2;            // [npieces+1] pieces: L at the start; [npieces] = L behind the last element
+    void *subs;                // [nsub+1] mss_subent: the pieces cut again at the speculative light edges inside them
+    int64_t dump_cap;          // dump slots
+    mss_cand *dump;            // [dump_cap][MSS_LCAP] LDS part of a sub-piece's stack at its end (what the stitch reads)
     mss_cand *stack;           // [nruns] overflow stack slots
     int32_t *segs;             // [nruns][2] kept segments in stretch-local slots
     int32_t *segs_out;         // [nruns][2] compacted
@@ -108,6 +127,9 @@ static mss_layout mss_carve(void *work, int64_t n)
     l.ustart2 = (int64_t *)take((2 * maxunits + 2) * 8);
     l.urun2 = (int64_t *)take((2 * maxunits + 2) * 8);
     l.entry2 = (double *)take((2 * maxunits + 2) * 8);
+    l.subs = take((3 * maxunits + 8) * (int64_t)MSS_SUBENT_BYTES);
+    l.dump_cap = 2 * (l.nblk / MSS_SUB_MIN + 2);
+    l.dump = (mss_cand *)take(l.dump_cap * MSS_LCAP * (int64_t)sizeof(mss_cand));
     l.stack = (mss_cand *)take(maxruns * (int64_t)sizeof(mss_cand));
     l.segs = (int32_t *)take(maxruns * 8);
     l.segs_out = (int32_t *)take(maxruns * 8);
@@ -340,34 +362,47 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                                                       const int32_t *__restrict__ blk_q, const uint8_t *__restrict__ flags,
                                                       const double *__restrict__ sup_sum, const double *__restrict__ sup_abs,
                                                       const int32_t *__restrict__ sup_q, const uint8_t *__restrict__ sup_flags,
-                                                      int have_stats, int independent, int cutmode)
+                                                      int have_stats, int independent, int cutmode,
+                                                      mss_subent *subs, mss_cand *dump_all)
 {
     __shared__ double2 sLR[MSS_LCAP];                           // (L, R)
-    __shared__ int4 sIdx[MSS_LCAP];                             // (st, en, pre, -)
+    __shared__ int4 sIdx[MSS_LCAP];                             // (st, en, pre, left-open)
     const int lane = threadIdx.x;
     const int64_t k = blockIdx.x;
-    const int64_t begin = ustart[k], end = ustart[k + 1];
-    volatile mss_cand *ovf = stack_all + urun[k];               // slots MSS_LCAP.. of this stretch's stack
-    int32_t *segs = segs_all + 2 * urun[k];
+    // sub-piece mode (subs != NULL, with cutmode): unit k is subs[k]; `head` = it opens its piece, `tail` = it ends it.  A unit that is
+    // not a head scans on a LOCAL stack: a candidate whose search runs off its bottom is pushed LEFT-OPEN (pad = 1) instead of flushing
+    // -- no flush can happen there (it would have been filed as a cut) -- and the stack is left for mss_stitch_kernel.
+    const bool sub = subs != nullptr;
+    const bool head = !sub || subs[k].first != 0;
+    const bool tail = !sub || k + 1 == nunits || subs[k + 1].first != 0;
+    const int64_t begin = sub ? subs[k].start : ustart[k], end = sub ? subs[k + 1].start : ustart[k + 1];
+    const int64_t slot0 = sub ? subs[k].run : urun[k];
+    volatile mss_cand *ovf = stack_all + slot0;                 // slots MSS_LCAP.. of this stretch's stack
+    int32_t *segs = segs_all + 2 * slot0;
     int64_t nst = 0, nseg = 0;
     // independent: every unit is a record of its own (a batch of records side by side): L starts at 0, the unit
     // ends with the end-of-sequence flush of mss.c:96, nothing is handed on
-    double cur = (k == 0 || independent) ? 0.0 : exit_prev[k - 1];   // L outside a run, R inside one
-    double peak = MSS_NEG;
-    bool run_open = false;
-    int64_t run_st = 0;
-    double run_L = 0.0;
+    double cur = sub ? subs[k].L : (k == 0 || independent) ? 0.0 : exit_prev[k - 1];   // L outside a run, R inside one
+    double peak = sub && !head ? subs[k].peak : MSS_NEG;
+    bool run_open = sub && !head && subs[k].open != 0;
+    int64_t run_st = run_open ? subs[k].run_st : 0;
+    double run_L = run_open ? subs[k].run_L : 0.0;
+    bool was_reset = false;
+    // (a part behind an edge cannot see the true stack's bottom: it follows the flush level as the light walk does -- mss.c:78-81 sets
+    // max = R there, and the x-drop test reads max.  Only a run that was open across the edge can flush behind it: every other flush
+    // is a cut)
+    double Lf = sub && !head ? subs[k].Lf : INFINITY;
 
-    struct cand_v { double L, R; int32_t st, en, pre; };
+    struct cand_v { double L, R; int32_t st, en, pre, open; };
     auto get = [&](int64_t j) -> cand_v {
         cand_v c;
         if (j < MSS_LCAP) {
             const double2 lr = sLR[j];
             const int4 ix = sIdx[j];
-            c.L = lr.x; c.R = lr.y; c.st = ix.x; c.en = ix.y; c.pre = ix.z;
+            c.L = lr.x; c.R = lr.y; c.st = ix.x; c.en = ix.y; c.pre = ix.z; c.open = ix.w;
         } else {
             volatile mss_cand *o = ovf + (j - MSS_LCAP);
-            c.L = o->L; c.R = o->R; c.st = o->st; c.en = o->en; c.pre = o->pre;
+            c.L = o->L; c.R = o->R; c.st = o->st; c.en = o->en; c.pre = o->pre; c.open = o->pad;
         }
         return c;
     };
@@ -398,6 +433,7 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
     // a positive run [run_st, en) with prefix values run_L (before) and R (after) is complete: mss.c:65-86
     auto close_run = [&](double R, int64_t en) {
         if (R > peak) peak = R;
+        if (!head && run_L <= Lf) { Lf = run_L; peak = R; }          // a flush in truth (the stitch does it; the search below runs off the bottom)
         int32_t tst = (int32_t)run_st;
         double tL = run_L;
         int64_t j;
@@ -417,20 +453,27 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
             }
             break;
         }
-        if (j < 0) { flush(); peak = R; }
+        const int lopen = j < 0 && !head ? 1 : 0;                // the search ran off a local stack: the stitch goes on from here
+        if (j < 0 && head) { flush(); peak = R; }
+        if (was_reset && lane == 0) { atomicOr((unsigned long long *)&grand[2], 1ull); atomicOr((unsigned long long *)&grand[4], 8ull); }   // (a run behind a reset opens the next piece)
         if (nst < MSS_LCAP) {
             if (lane == 0) {
                 sLR[nst] = make_double2(tL, R);
-                sIdx[nst] = make_int4(tst, (int32_t)en, (int32_t)j, 0);
+                sIdx[nst] = make_int4(tst, (int32_t)en, (int32_t)j, lopen);
             }
         } else {
             // every lane stores the same record, so each lane later reads what it wrote itself
             volatile mss_cand *c = ovf + (nst - MSS_LCAP);
-            c->st = tst; c->en = (int32_t)en; c->L = tL; c->R = R; c->pre = (int32_t)j;
+            c->st = tst; c->en = (int32_t)en; c->L = tL; c->R = R; c->pre = (int32_t)j; c->pad = lopen;
         }
         __threadfence_block();
         ++nst;
         run_open = false;
+    };
+    // x-drop reset (mss.c:89-92): everything is moved out.  On a local stack that is the stitch's job: the piece ends with this unit
+    // (the next closed run is a cut), so the flush at the end of the piece IS this one.
+    auto reset_flush = [&]() {
+        if (head) flush(); else { was_reset = true; Lf = INFINITY; }
     };
 
     int64_t pos = begin;
@@ -512,10 +555,12 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
             if (nst >= 1 && nst <= MSS_LCAP) {
                 const cand_v c0 = get(nst - 1);
                 const int64_t nb = c0.pre;
-                const bool lone = nst == 1;                                        // (then pre = -1)
+                // (a LEFT-OPEN top, on a local stack: merged into it the run's search runs off the bottom again -- the top pushed again,
+                // left-open, with the run's end; no flush, max as with a neighbour that is never exceeded)
+                const bool lone = nst == 1 && !c0.open;                            // (then pre = -1)
                 double lim = INFINITY;                                             // the neighbour's R: an end above it merges again
                 if (!lone && nb >= 0) lim = get(nb).R;
-                if (lone || nb >= 0) {
+                if (lone || nb >= 0 || c0.open) {
                 const double V = base + pre;
                 const bool edge_close = run_open && !(mpos & 1ull);          // the open run ended with the previous chunk
                 const bool isend = ispos && lane + 1 < nvalid && !((mpos >> (lane + 1)) & 1ull);
@@ -547,7 +592,7 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                         const double newR = mend ? lane_value(V, last) : cur;
                         if (lane == 0) {
                             sLR[nst - 1] = make_double2(c0.L, newR);
-                            sIdx[nst - 1] = make_int4(c0.st, (int32_t)(pos + last + 1), (int32_t)nb, 0);
+                            sIdx[nst - 1] = make_int4(c0.st, (int32_t)(pos + last + 1), (int32_t)nb, c0.open);
                         }
                         __threadfence_block();
                         peak = lone ? newR : (newR > peak ? newR : peak);
@@ -588,7 +633,7 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                         const unsigned long long mt = __ballot(trig);
                         if (mt) {
                             const int t = __builtin_ctzll(mt);
-                            flush();
+                            reset_flush();
                             peak = MSS_NEG;
                             if (cert) base = t == 0 ? 0.0 : -lane_value(pre, t - 1);   // L = 0 before S[t] is added
                             else pre = mss_fold(s, 0.0, t, nvalid, lane);
@@ -607,25 +652,171 @@ __global__ void __launch_bounds__(64) mss_scan_kernel(const double *__restrict__
                     cur = cur + v;
                 } else {
                     if (run_open) close_run(cur, pos + i);
-                    if (xdrop > 0.0 && cur + v + xdrop < peak) { flush(); cur = 0.0; peak = MSS_NEG; }
+                    if (xdrop > 0.0 && cur + v + xdrop < peak) { reset_flush(); cur = 0.0; peak = MSS_NEG; }
                     cur += v;
                 }
             }
         }
         pos += nvalid;
     }
-    if (run_open) close_run(cur, end);
-    if (k == nunits - 1 || independent || cutmode) {
+    if (run_open && tail) close_run(cur, end);                // (a run open at a speculative edge goes on in the next unit)
+    if (sub && !(head && tail)) {
+        // part of a longer piece: the stack stays as it is for mss_stitch_kernel -- its first MSS_LCAP candidates from LDS to the
+        // unit's dump slot (a head: the slot behind its first edge's), the deeper ones are in the unit's own stack slots already
+        const int64_t slot = head ? 2 * (int64_t)subs[k + 1].vci + 1 : 2 * (int64_t)subs[k].vci;
+        mss_cand *d = dump_all + slot * MSS_LCAP;
+        for (int64_t j = lane; j < nst && j < MSS_LCAP; j += 64) {
+            const double2 lr = sLR[j];
+            const int4 ix = sIdx[j];
+            mss_cand c;
+            c.st = ix.x; c.en = ix.y; c.L = lr.x; c.R = lr.y; c.pre = ix.z; c.pad = ix.w;
+            d[j] = c;
+        }
+        if (lane == 0) {
+            subs[k].nst = (int32_t)(nst < (1ll << 31) ? nst : -1);
+            subs[k].reset = was_reset ? 1 : 0;
+        }
+    } else if (k == nunits - 1 || independent || cutmode) {
         flush();                                              // (cutmode: the next piece opens with a flush, mss_light_kernel)
     } else if (nst != 0 || peak != MSS_NEG) {
         if (lane == 0) atomicOr((unsigned long long *)&grand[2], 1ull);   // forced-reset argument failed: caller falls back
     }
     if (lane == 0) {
         segcnt[k] = (uint64_t)nseg;
-        if (!independent && (pass == 0 || __double_as_longlong(exit_prev[k]) != __double_as_longlong(cur)))
+        const double want = sub ? subs[k + 1].L : exit_prev[k];
+        if (!independent && (pass == 0 || __double_as_longlong(want) != __double_as_longlong(cur)))
             atomicOr((unsigned long long *)&grand[1], 1ull);
         exit_cur[k] = cur;
     }
+}
+
+// The stitch of a piece that was scanned in parts (one wave per piece head).  The head's stack is the reference's own; every later
+// part left a local stack whose candidates are CLOSED -- their search stopped inside the part: every comparison they made holds
+// against the true stack as well (a left-open candidate's true L can only be smaller than its local one, its R is exact) -- or
+// LEFT-OPEN: their search ran off the local bottom.  In order: a closed candidate is appended (its `pre` moved by the distance its
+// part's bottom-most left-open candidate in front of it moved); a left-open one runs mss.c:66-86 against the true stack.  A
+// left-open candidate that grew by absorbing later runs stands for the whole chain of its extensions: R only grew along the chain, so
+// what the last extension merges with contains what every earlier one merged with, and the candidates pushed in between were absorbed.
+__global__ void __launch_bounds__(64) mss_stitch_kernel(mss_subent *subs, int64_t nunits, mss_cand *stack_all, const mss_cand *dump_all,
+                                                        int32_t *__restrict__ segs_all, uint64_t *__restrict__ segcnt, int min_sc,
+                                                        uint64_t *__restrict__ grand)
+{
+    const int lane = threadIdx.x;
+    const int64_t k = blockIdx.x;
+    if (!subs[k].first || k + 1 >= nunits || subs[k + 1].first) return;           // heads of pieces with more than one part only
+    __shared__ mss_cand loc[256];
+    volatile mss_cand *T = stack_all + subs[k].run;                                // the true stack, in the piece's own slots
+    int64_t nT = subs[k].nst;
+    bool bad = nT < 0;
+    // the head's stack: slots j - MSS_LCAP hold candidate j >= MSS_LCAP; move them up (from the top down), then the LDS part in front
+    if (!bad) {
+        for (int64_t hi = nT; hi > MSS_LCAP; hi -= 64) {
+            const int64_t j = hi - 1 - lane;                                           // this lane's candidate of the chunk [hi - 64, hi)
+            mss_cand c;
+            const bool on = j >= MSS_LCAP;
+            if (on) { volatile mss_cand *o = T + (j - MSS_LCAP); c.st = o->st; c.en = o->en; c.L = o->L; c.R = o->R; c.pre = o->pre; c.pad = 0; }
+            __threadfence_block();
+            if (on) { volatile mss_cand *o = T + j; o->st = c.st; o->en = c.en; o->L = c.L; o->R = c.R; o->pre = c.pre; o->pad = 0; }
+            __threadfence_block();
+        }
+        const mss_cand *d = dump_all + (2 * (int64_t)subs[k + 1].vci + 1) * MSS_LCAP;
+        for (int64_t j = lane; j < nT && j < MSS_LCAP; j += 64) {
+            const mss_cand c = d[j];
+            volatile mss_cand *o = T + j; o->st = c.st; o->en = c.en; o->L = c.L; o->R = c.R; o->pre = c.pre; o->pad = 0;
+        }
+        __threadfence();
+    }
+    int64_t nseg = (int64_t)segcnt[k];
+    int32_t *segs = segs_all + 2 * subs[k].run;
+    // mss.c:35-47 over the true stack
+    auto flush_T = [&]() {
+        for (int64_t base = 0; base < nT; base += 64) {
+            const int64_t j = base + lane;
+            bool keep = false;
+            int32_t a = 0, b = 0;
+            if (j < nT) {
+                volatile mss_cand *c = T + j;
+                keep = c->R - c->L >= min_sc;
+                a = c->st;
+                b = c->en;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int64_t slot = nseg + __popcll(m & ((1ull << lane) - 1ull));
+                segs[2 * slot] = a;
+                segs[2 * slot + 1] = b;
+            }
+            nseg += __popcll(m);
+        }
+        nT = 0;
+    };
+    for (int64_t u = k + 1; !bad && u < nunits && !subs[u].first; ++u) {
+        const int64_t nl = subs[u].nst;
+        if (nl < 0) { bad = true; break; }
+        // the part's candidates pass through a window of 256 in LDS, loaded 64 at a time well ahead of their turn: its deeper ones
+        // (index >= MSS_LCAP) lie in the part's own stack slots, which the true stack may grow into -- by at most one slot per
+        // candidate processed, from a start at or below the part's first slot (checked)
+        const mss_cand *d = dump_all + 2 * (int64_t)subs[u].vci * MSS_LCAP;
+        const mss_cand *deep = stack_all + subs[u].run;
+        if (nl > MSS_LCAP && subs[k].run + nT > subs[u].run) { bad = true; break; }
+        int64_t w = 0;
+        auto load_chunk = [&]() {
+            const int64_t j = w + lane;
+            if (j < nl) loc[j & 255] = j < MSS_LCAP ? d[j] : deep[j - MSS_LCAP];
+            w += 64;
+        };
+        __syncthreads();
+        while (w < nl && w < 256) load_chunk();
+        __syncthreads();
+        int64_t delta = 0;
+        for (int64_t i = 0; i < nl && !bad; ++i) {
+            if (w < nl && i + 192 >= w) {
+                if (subs[k].run + nT > subs[u].run + w - MSS_LCAP) { bad = true; break; }
+                __syncthreads();
+                load_chunk();
+                __syncthreads();
+            }
+            const mss_cand e = loc[i & 255];
+            int32_t tst = e.st, pre;
+            double tL = e.L;
+            if (e.pad) {
+                int64_t j;
+                for (;;) {
+                    j = nT - 1;
+                    double cL = 0.0, cR = 0.0;
+                    int32_t cst = 0;
+                    while (j >= 0) {
+                        volatile mss_cand *c = T + j;
+                        cL = c->L;
+                        if (cL < tL) { cR = c->R; cst = c->st; break; }
+                        const int32_t pr = c->pre;
+                        j = pr >= 0 ? pr : j - 1;
+                    }
+                    if (j >= 0 && cR < e.R) { tst = cst; tL = cL; nT = j; continue; }
+                    break;
+                }
+                // no candidate with a smaller L: mss.c:78-81 moves the stack out -- nothing, if the candidate has absorbed it down to the
+                // piece's bottom; else a run that was open across the edge flushes (any other flush would have been a cut)
+                if (j < 0 && nT > 0) flush_T();
+                pre = (int32_t)j;
+                delta = nT - i;
+            } else {
+                if (i == 0 || e.pre < 0) { bad = true; if (lane == 0) atomicOr((unsigned long long *)&grand[4], 4ull); break; }   // (a local stack starts with a left-open candidate)
+                pre = (int32_t)(e.pre + delta);
+            }
+            volatile mss_cand *o = T + nT;
+            o->st = tst; o->en = e.en; o->L = tL; o->R = e.R; o->pre = pre; o->pad = 0;
+            __threadfence();
+            ++nT;
+        }
+    }
+    if (bad) {
+        if (lane == 0) atomicOr((unsigned long long *)&grand[2], 1ull);
+        return;
+    }
+    // the flush at the piece's end (mss.c:35-47), behind what the head and the stitch flushed on the way
+    flush_T();
+    if (lane == 0) segcnt[k] = (uint64_t)nseg;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -960,14 +1151,67 @@ __global__ void __launch_bounds__(256) mss_pieces_kernel(const int64_t *__restri
     }
 }
 
+// ---- the pieces cut again at the speculative light edges inside them (mss_subent) ------------------------------------------------
+__device__ __forceinline__ int64_t mss_lower_bound(const int64_t *a, int64_t n, int64_t x)       // first i with a[i] >= x
+{
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// valid[j] = light unit j starts at a speculative edge that is not a piece start (then scanned: compact index of the edge)
+__global__ void __launch_bounds__(256) mss_specvalid_kernel(const int64_t *__restrict__ lstart, const uint8_t *__restrict__ lforced, int64_t nl,
+                                                            const int64_t *__restrict__ pstart, int64_t np, uint64_t *__restrict__ valid)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nl) return;
+    bool v = j >= 1 && j < nl && !lforced[j];
+    if (v) {
+        const int64_t at = mss_lower_bound(pstart, np, lstart[j]);
+        v = !(at < np && pstart[at] == lstart[j]);
+    }
+    valid[j] = v ? 1 : 0;
+}
+// pieces and valid edges merged by position; subs[nsub] = the end sentinel
+__global__ void __launch_bounds__(256) mss_subtable_kernel(const int64_t *__restrict__ lstart, const int64_t *__restrict__ lrun,
+                                                           const uint8_t *__restrict__ lforced, int64_t nl, const mss_light_state *__restrict__ lst,
+                                                           const uint64_t *__restrict__ vc, const uint64_t *__restrict__ nv_p,
+                                                           const int64_t *__restrict__ pstart, const int64_t *__restrict__ prun,
+                                                           const double *__restrict__ pentry, int64_t np, int64_t n, mss_subent *__restrict__ subs)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nv = (int64_t)*nv_p;
+    if (i < np) {
+        const int64_t jx = mss_lower_bound(lstart, nl + 1, pstart[i]);            // edges in front of the piece: units j < jx
+        mss_subent e = {};
+        e.start = pstart[i]; e.run = prun[i]; e.L = pentry[i]; e.peak = MSS_NEG; e.first = 1; e.vci = -1; e.nst = 0;
+        subs[i + (int64_t)vc[jx]] = e;
+    }
+    if (i >= 1 && i < nl && !lforced[i]) {
+        const bool valid = vc[i + 1] != vc[i];
+        if (valid) {
+            const int64_t pb = mss_lower_bound(pstart, np, lstart[i] + 1);        // pieces that start at or in front of the edge
+            const mss_light_state st = lst[i - 1];
+            mss_subent e = {};
+            e.start = lstart[i]; e.run = lrun[i]; e.L = st.L; e.peak = st.peak; e.run_L = st.run_L; e.run_st = st.run_st;
+            e.open = st.open != 0; e.first = 0; e.vci = (int32_t)vc[i]; e.nst = 0; e.Lf = st.Lf;
+            subs[pb + (int64_t)vc[i]] = e;
+        }
+    }
+    if (i == 0) {
+        mss_subent e = {};
+        e.start = n; e.first = 1; e.L = pentry[np]; e.vci = -1;
+        subs[np + nv] = e;
+    }
+}
+
 __global__ void __launch_bounds__(256) mss_compact_kernel(const int32_t *__restrict__ segs, const int64_t *__restrict__ urun,
                                                           const uint64_t *__restrict__ segoff, const uint64_t *__restrict__ segcnt_total,
-                                                          int64_t nunits, int32_t *__restrict__ out)
+                                                          int64_t nunits, int32_t *__restrict__ out, const mss_subent *__restrict__ subs)
 {
     // one thread per stretch copies its kept segments to their global slots (order preserved)
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nunits) return;
-    const int64_t from = urun[k];
+    const int64_t from = subs ? subs[k].run : urun[k];
     const uint64_t to = segoff[k];
     const uint64_t cnt = (k + 1 < nunits ? segoff[k + 1] : *segcnt_total) - to;
     for (uint64_t j = 0; j < cnt; ++j) {
@@ -1142,10 +1386,64 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
                 DGRP_HIP(hipMemcpyAsync(l.ustart2 + npieces, &n, 8, hipMemcpyHostToDevice, stream));
                 DGRP_HIP(hipMemcpyAsync(l.entry2 + npieces, (const mss_light_state *)l.lstate[pass & 1] + (nl - 1), 8, hipMemcpyDeviceToDevice,
                                         stream));   // .L is the first field
+                // ---- third level: a piece that spans speculative light edges is scanned in parts, all at once, each on a local stack
+                // from the edge's converged state, and stitched (mss_subent, mss_stitch_kernel).  Anything the stitch does not take -- a
+                // local stack deeper than the LDS part, an impossible event -- sends the pieces through the scan whole, as before.
+                bool sub_done = false;
+                mss_subent *subs = (mss_subent *)l.subs;
+                if (nl > 1 && xdrop > 0.0 && !getenv("DGRP_MSS_NO_SUB")) {
+                    const char *e = getenv("DGRP_MSS_SUB");
+                    const int sub = e && atoi(e) > 0 ? atoi(e) : MSS_LIGHT_SUB;
+                    if (sub >= MSS_SUB_MIN) {
+                        hipLaunchKernelGGL(mss_specvalid_kernel, dim3((unsigned)((nl + 1 + 255) / 256)), dim3(256), 0, stream, l.lstart, l.lforced,
+                                           nl, l.ustart2, npieces, l.lblk);
+                        DGRP_LAUNCH_CHECK();
+                        int rcv = device_exclusive_scan(l.lblk, l.lblk, nl + 1, l.tiles, l.grand + 7, stream);
+                        if (rcv) return rcv;
+                        uint64_t nv = 0;
+                        DGRP_HIP(hipMemcpyAsync(&nv, l.grand + 7, 8, hipMemcpyDeviceToHost, stream));
+                        DGRP_HIP(hipStreamSynchronize(stream));
+                        if (nv > 0 && 2 * (int64_t)nv + 2 <= l.dump_cap && npieces + (int64_t)nv <= l.nblk) {   // (segcnt / exitL hold nblk + 1 units)
+                            const int64_t nsub = npieces + (int64_t)nv;
+                            const int64_t threads = (npieces > nl ? npieces : nl) + 1;
+                            hipLaunchKernelGGL(mss_subtable_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, l.lstart, l.lrun,
+                                               l.lforced, nl, (const mss_light_state *)l.lstate[pass & 1], l.lblk, l.grand + 7, l.ustart2,
+                                               l.urun2, l.entry2, npieces, n, subs);
+                            DGRP_LAUNCH_CHECK();
+                            DGRP_HIP(hipMemsetAsync(l.grand + 1, 0, 16, stream));
+                            DGRP_HIP(hipMemsetAsync(l.grand + 4, 0, 8, stream));
+                            hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)nsub), dim3(64), 0, stream, d_scores, l.ustart2, l.urun2, nsub,
+                                               l.entry2 + 1, l.exitL[(pass + 1) & 1], l.stack, l.segs, l.segcnt, min_sc, xdrop, l.grand, 1,
+                                               l.blk_sum, l.blk_abs, l.blk_q, l.flags, l.sup_sum, l.sup_abs, l.sup_q, l.sup_flags, 1, 0, 1, subs,
+                                               l.dump);
+                            DGRP_LAUNCH_CHECK();
+                            hipLaunchKernelGGL(mss_stitch_kernel, dim3((unsigned)nsub), dim3(64), 0, stream, subs, nsub, l.stack, l.dump, l.segs,
+                                               l.segcnt, min_sc, l.grand);
+                            DGRP_LAUNCH_CHECK();
+                            uint64_t g[5] = { 0, 0, 0, 0, 0 };
+                            DGRP_HIP(hipMemcpyAsync(g, l.grand, 40, hipMemcpyDeviceToHost, stream));
+                            DGRP_HIP(hipStreamSynchronize(stream));
+                            if (getenv("DGRP_MSS_TRACE"))
+                                fprintf(stderr, "dgrp_mss_labels: %lld pieces in %lld parts (%llu speculative edges inside pieces)%s (exit %llu, error %llu, why %llu)\n",
+                                        (long long)npieces, (long long)nsub, (unsigned long long)nv, g[1] || g[2] ? ": not stitched" : "",
+                                        (unsigned long long)g[1], (unsigned long long)g[2], (unsigned long long)g[4]);
+                            if (!g[1] && !g[2]) {
+                                int rc3 = device_exclusive_scan(l.segcnt, l.segcnt, nsub, l.tiles, l.grand + 3, stream);
+                                if (rc3) return rc3;
+                                hipLaunchKernelGGL(mss_compact_kernel, dim3((unsigned)((nsub + 255) / 256)), dim3(256), 0, stream, l.segs,
+                                                   l.urun2, l.segcnt, l.grand + 3, nsub, l.segs_out, (const mss_subent *)subs);
+                                DGRP_LAUNCH_CHECK();
+                                done = sub_done = true;
+                            }
+                        }
+                    }
+                }
+                if (!sub_done) {
                 DGRP_HIP(hipMemsetAsync(l.grand + 1, 0, 16, stream));
                 hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)npieces), dim3(64), 0, stream, d_scores, l.ustart2, l.urun2, npieces,
                                    l.entry2 + 1, l.exitL[(pass + 1) & 1], l.stack, l.segs, l.segcnt, min_sc, xdrop, l.grand, 1, l.blk_sum,
-                                   l.blk_abs, l.blk_q, l.flags, l.sup_sum, l.sup_abs, l.sup_q, l.sup_flags, 1, 0, 1);
+                                   l.blk_abs, l.blk_q, l.flags, l.sup_sum, l.sup_abs, l.sup_q, l.sup_flags, 1, 0, 1, (mss_subent *)nullptr,
+                                   (mss_cand *)nullptr);
                 DGRP_LAUNCH_CHECK();
                 uint64_t g[3] = { 0, 0, 0 };
                 DGRP_HIP(hipMemcpyAsync(g, l.grand, 24, hipMemcpyDeviceToHost, stream));
@@ -1154,9 +1452,10 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
                     int rc3 = device_exclusive_scan(l.segcnt, l.segcnt, npieces, l.tiles, l.grand + 3, stream);
                     if (rc3) return rc3;
                     hipLaunchKernelGGL(mss_compact_kernel, dim3((unsigned)((npieces + 255) / 256)), dim3(256), 0, stream, l.segs, l.urun2,
-                                       l.segcnt, l.grand + 3, npieces, l.segs_out);
+                                       l.segcnt, l.grand + 3, npieces, l.segs_out, (const mss_subent *)nullptr);
                     DGRP_LAUNCH_CHECK();
                     done = true;
+                }
                 }
             }
             if (done) break;
@@ -1171,7 +1470,7 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
             hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)nunits), dim3(64), 0, stream, d_scores, l.ustart, l.urun,
                                nunits, l.exitL[(pass + 1) & 1], l.exitL[pass & 1], l.stack, l.segs, l.segcnt, min_sc, xdrop,
                                l.grand, pass, l.blk_sum, l.blk_abs, l.blk_q, l.flags, l.sup_sum, l.sup_abs, l.sup_q,
-                               l.sup_flags, 1, 0, 0);
+                               l.sup_flags, 1, 0, 0, (mss_subent *)nullptr, (mss_cand *)nullptr);
             DGRP_LAUNCH_CHECK();
             uint64_t g[3] = { 0, 0, 0 };
             DGRP_HIP(hipMemcpyAsync(g, l.grand, 24, hipMemcpyDeviceToHost, stream));
@@ -1189,7 +1488,7 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
         int rc = device_exclusive_scan(l.segcnt, l.segcnt, nunits, l.tiles, l.grand + 3, stream);
         if (rc) return rc;
         hipLaunchKernelGGL(mss_compact_kernel, dim3((unsigned)((nunits + 255) / 256)), dim3(256), 0, stream, l.segs, l.urun,
-                           l.segcnt, l.grand + 3, nunits, l.segs_out);
+                           l.segcnt, l.grand + 3, nunits, l.segs_out, (const mss_subent *)nullptr);
         DGRP_LAUNCH_CHECK();
         break;
     }
@@ -1266,12 +1565,12 @@ DGRP_EXPORT int dgrp_mss_labels_batch(const double *d_scores, const int8_t *d_cl
     DGRP_HIP(hipMemsetAsync(l.grand, 0, 64, stream));
     hipLaunchKernelGGL(mss_scan_kernel, dim3((unsigned)nrec), dim3(64), 0, stream, d_scores, l.ustart, l.urun, nrec, l.exitL[1],
                        l.exitL[0], l.stack, l.segs, l.segcnt, min_sc, xdrop, l.grand, 0, l.blk_sum, l.blk_abs, l.blk_q, l.flags,
-                       l.sup_sum, l.sup_abs, l.sup_q, l.sup_flags, 1, 1, 0);
+                       l.sup_sum, l.sup_abs, l.sup_q, l.sup_flags, 1, 1, 0, (mss_subent *)nullptr, (mss_cand *)nullptr);
     DGRP_LAUNCH_CHECK();
     int rc = device_exclusive_scan(l.segcnt, l.segcnt, nrec, l.tiles, l.grand + 3, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(mss_compact_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, stream, l.segs, l.urun, l.segcnt,
-                       l.grand + 3, nrec, l.segs_out);
+                       l.grand + 3, nrec, l.segs_out, (const mss_subent *)nullptr);
     DGRP_LAUNCH_CHECK();
     DGRP_HIP(hipMemcpyAsync(d_labels_out, d_cls, total_n, hipMemcpyDeviceToDevice, stream));
     hipLaunchKernelGGL(mss_vote_kernel, dim3(1024), dim3(256), 0, stream, l.segs_out, l.grand + 3, d_cls, nof_labels, d_labels_out);

@@ -459,6 +459,46 @@ def test_mss_speculative_units(L, dev, orc, sub, drift, exact, xd, monkeypatch):
     np.testing.assert_array_equal(buf[:len(segs)], np.array([(a, b) for a, b, _ in segs], np.int32).reshape(-1, 2))
 
 
+@pytest.mark.parametrize("drift,exact", [(0.3, True), (0.3, False), (0.05, True), (0.0, False), (-0.02, True), (0.6, False)])
+@pytest.mark.parametrize("xd", [50, 3])
+def test_mss_stitched_pieces(L, dev, orc, drift, exact, xd, monkeypatch, capfd):
+    """A piece that spans speculative light edges (units of 256 64-blocks here) is scanned in parts -- each on a local stack from the
+    edge's converged state -- and stitched (mss_stitch_kernel): upward drift (one piece, one ever-growing candidate under which the
+    excursions pile up), no drift (pieces of every length, deep-ish local stacks), a forced reset and x-drop resets in between."""
+    monkeypatch.setenv("DGRP_MSS_SUB", "256")
+    monkeypatch.setenv("DGRP_MSS_TRACE", "1")
+    rng = np.random.default_rng(int(drift * 100) + xd + (17 if exact else 0))
+    n = 300_007
+    scores = rng.normal(drift, 1.0, size=n)
+    if exact:
+        scores = np.round(scores * 1024) / 1024
+    else:
+        scores[::7] *= 2.0 ** -17
+        scores[:2000] += 3000.0
+    scores[rng.random(n) < 0.01] = 0.0
+    scores[140_000:140_200] = -40.0                                       # a forced reset
+    scores[200_000:200_040] = -3.0                                        # a dip that may fire the x-drop inside a piece
+    cls = rng.integers(0, 5, size=n).astype(np.int64)
+    want, segs = orc.find_mss_labels(scores, cls, 5, 3, xd, return_segments=True)
+    d_s, d_l = _t(scores, dev), _t(cls.astype(np.int8), dev)
+    lab = torch.empty(n, dtype=torch.int8, device=dev)
+    wb = L.dgrp_mss_workspace_bytes(n)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    nseg = torch.zeros(1, dtype=torch.int64, device=dev)
+    _check(L.dgrp_mss_labels(d_s.data_ptr(), d_l.data_ptr(), n, 5, 3, xd, lab.data_ptr(), nseg.data_ptr(),
+                             work.data_ptr(), wb, _sp()))
+    torch.cuda.synchronize()
+    err = capfd.readouterr().err
+    assert int(nseg.item()) == len(segs)
+    np.testing.assert_array_equal(lab.cpu().numpy(), want)
+    buf = np.zeros((max(len(segs), 1), 2), np.int32)
+    cnt = C.c_int64()
+    _check(L.dgrp_mss_segments_host(work.data_ptr(), work.numel(), buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
+    np.testing.assert_array_equal(buf[:len(segs)], np.array([(a, b) for a, b, _ in segs], np.int32).reshape(-1, 2))
+    if drift >= 0.3:
+        assert "parts (" in err and "not stitched" not in err, err        # the upward drift is the case this path exists for
+
+
 def test_softmax_path_golden(L, dev):
     g = golden("softmax.npz")
     probs = g["probs"]

@@ -1,6 +1,6 @@
 """dgrp_mss_labels on score arrays WITHOUT the structure of a genome (the serial cliff of VERDICT r01 #5): 10 M scores per style,
 wall clock of the whole labels stage and -- with DGRP_MSS_TRACE=1 -- stretches / light units / passes.
-    python tools/mss_cliff.py [Mscores] [check]      (check: compare with the oracle; minutes of CPU for 10 M)"""
+    python tools/mss_cliff.py [Mscores] [check|nocheck] [style substring]      (check: compare with the oracle; minutes of CPU for 10 M)"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +28,10 @@ styles = {
     "normal(-0.3, 1): downward drift (a flush at almost every run)": lambda: (rng.normal(-0.3, 1, n), rng.integers(0, 5, n)),
     "normal(-0.02, 1): slow downward drift, x-drop resets": lambda: (rng.normal(-0.02, 1, n), rng.integers(0, 5, n)),
 }
+only = sys.argv[3] if len(sys.argv) > 3 else ""
 for name, make in styles.items():
+    if only not in name:
+        continue
     S, cls = make()
     d_S = torch.from_numpy(np.ascontiguousarray(S, np.float64)).to(dev)
     d_c = torch.from_numpy(cls.astype(np.int8)).to(dev)
