@@ -29,6 +29,8 @@
 //      serial.  Whole all-non-positive 64-blocks are skipped 64 at a time in the history-free
 //      state under the same certificate.  A chunk whose certificate fails is folded element by
 //      element.
+//  Further levels below: flush cuts (mss_light_kernel), speculative light units, the growing-candidate shortcut, and pieces scanned
+//  in parts and stitched (mss_subent, mss_stitch_kernel) -- DESIGN.md 3.3 lists all eight devices.
 // ------------------------------------------------------------------------------------------
 struct mss_cand { int32_t st, en; double L, R; int32_t pre, pad; };   // mss.c:24-28
 
@@ -1222,14 +1224,28 @@ __global__ void __launch_bounds__(256) mss_compact_kernel(const int32_t *__restr
 
 // A9  deepgrp/_mss/pymss.pyx:57-77: one wave per kept segment: majority label over 1..C-1 (first
 // maximum wins, all-zero segment -> 1), zeros inside the segment take it.
+#define MSS_VOTE_LONG 65536       // a longer segment is voted on by the whole grid (mss_vote_long_kernel): one wave walked a 10 M-base
+#define MSS_VOTE_CHUNK 16384      // segment for 73 ms
 __global__ void __launch_bounds__(256) mss_vote_kernel(const int32_t *__restrict__ segs, const uint64_t *__restrict__ nseg_p,
                                                        const int8_t *__restrict__ cls, int nof_labels,
-                                                       int8_t *__restrict__ out)
+                                                       int8_t *__restrict__ out, unsigned long long *__restrict__ nlong,
+                                                       int32_t *__restrict__ longlist, int64_t longcap)
 {
     const int lane = threadIdx.x & 63;
     const int64_t nseg = (int64_t)*nseg_p;
     for (int64_t sidx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sidx < nseg; sidx += (int64_t)gridDim.x * 4) {
         const int64_t st = segs[2 * sidx], en = segs[2 * sidx + 1];
+        if (nlong && en - st > MSS_VOTE_LONG) {
+            // filed for the whole grid: [0, longcap) segment indices, behind them 16 counters per filed segment
+            unsigned long long q = 0;
+            if (lane == 0) q = atomicAdd(nlong, 1ull);
+            q = __shfl(q, 0);
+            if ((int64_t)q < longcap) {
+                if (lane == 0) longlist[q] = (int32_t)sidx;
+                if (lane < 16) longlist[longcap + 16 * q + lane] = 0;
+                continue;
+            }
+        }
         int cnt[16];
 #pragma unroll
         for (int c = 0; c < 16; ++c) cnt[c] = 0;
@@ -1249,6 +1265,73 @@ __global__ void __launch_bounds__(256) mss_vote_kernel(const int32_t *__restrict
         for (int64_t j = st + lane; j < en; j += 64)
             if (cls[j] == 0) out[j] = (int8_t)best;
     }
+}
+
+// the long segments: PHASE 0 counts the classes chunk by chunk over the whole grid, PHASE 1 picks the label (pymss.pyx:57-77: first
+// maximum over 1..C-1, all-zero -> 1) and fills the zeros
+template <int PHASE>
+__global__ void __launch_bounds__(256) mss_vote_long_kernel(const int32_t *__restrict__ segs, const int8_t *__restrict__ cls, int nof_labels,
+                                                            int8_t *__restrict__ out, const unsigned long long *__restrict__ nlong,
+                                                            int32_t *__restrict__ longlist, int64_t longcap)
+{
+    const int64_t nq = (int64_t)min((unsigned long long)longcap, *nlong);
+    for (int64_t q = 0; q < nq; ++q) {
+        const int64_t sidx = longlist[q];
+        const int64_t st = segs[2 * sidx], en = segs[2 * sidx + 1];
+        int32_t *hist = longlist + longcap + 16 * q;
+        int best = 1;
+        if (PHASE == 1) {
+            int bv = hist[1];
+            for (int c = 2; c < nof_labels && c < 16; ++c)
+                if (bv < hist[c]) { best = c; bv = hist[c]; }
+        }
+        for (int64_t c0 = st + (int64_t)blockIdx.x * MSS_VOTE_CHUNK; c0 < en; c0 += (int64_t)gridDim.x * MSS_VOTE_CHUNK) {
+            const int64_t c1 = min(c0 + (int64_t)MSS_VOTE_CHUNK, en);
+            if (PHASE == 0) {
+                __shared__ int sh[16];
+                if (threadIdx.x < 16) sh[threadIdx.x] = 0;
+                __syncthreads();
+                int cnt[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) cnt[c] = 0;
+                for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) {
+                    const int l = cls[j];
+#pragma unroll
+                    for (int c = 1; c < 16; ++c) cnt[c] += (l == c);
+                }
+#pragma unroll
+                for (int c = 1; c < 16; ++c) {
+                    int v = cnt[c];
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh[c], v);
+                }
+                __syncthreads();
+                if (threadIdx.x >= 1 && threadIdx.x < 16 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+                __syncthreads();
+            } else {
+                for (int64_t j = c0 + threadIdx.x; j < c1; j += 256)
+                    if (cls[j] == 0) out[j] = (int8_t)best;
+            }
+        }
+    }
+}
+
+// A9 over the kept segments (l.segs_out, count in grand[3]); l.segs is free by now: the list of the long ones and their counters
+static int mss_vote_all(const mss_layout &l, const int8_t *d_cls, int nof_labels, int8_t *d_labels_out, int64_t n, hipStream_t stream)
+{
+    const int64_t longcap = n / MSS_VOTE_LONG + 1;                 // (17 longcap ints <= the 2 (n / 2 + 2) of l.segs)
+    unsigned long long *nlong = (unsigned long long *)l.grand;     // grand[0]: the scans are done with it
+    DGRP_HIP(hipMemsetAsync(nlong, 0, 8, stream));
+    hipLaunchKernelGGL(mss_vote_kernel, dim3(1024), dim3(256), 0, stream, l.segs_out, l.grand + 3, d_cls, nof_labels, d_labels_out, nlong,
+                       l.segs, longcap);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mss_vote_long_kernel<0>, dim3(1024), dim3(256), 0, stream, l.segs_out, d_cls, nof_labels, d_labels_out, nlong, l.segs,
+                       longcap);
+    DGRP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mss_vote_long_kernel<1>, dim3(1024), dim3(256), 0, stream, l.segs_out, d_cls, nof_labels, d_labels_out, nlong, l.segs,
+                       longcap);
+    DGRP_LAUNCH_CHECK();
+    return DGRP_OK;
 }
 
 DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int64_t n, int nof_labels,
@@ -1493,9 +1576,10 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
         break;
     }
     DGRP_HIP(hipMemcpyAsync(d_labels_out, d_cls, n, hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL(mss_vote_kernel, dim3(1024), dim3(256), 0, stream, l.segs_out, l.grand + 3, d_cls, nof_labels,
-                       d_labels_out);
-    DGRP_LAUNCH_CHECK();
+    {
+        const int rcv = mss_vote_all(l, d_cls, nof_labels, d_labels_out, n, stream);
+        if (rcv) return rcv;
+    }
     if (d_nseg) DGRP_HIP(hipMemcpyAsync(d_nseg, l.grand + 3, 8, hipMemcpyDeviceToDevice, stream));
     return DGRP_OK;
 }
@@ -1573,7 +1657,8 @@ DGRP_EXPORT int dgrp_mss_labels_batch(const double *d_scores, const int8_t *d_cl
                        l.grand + 3, nrec, l.segs_out, (const mss_subent *)nullptr);
     DGRP_LAUNCH_CHECK();
     DGRP_HIP(hipMemcpyAsync(d_labels_out, d_cls, total_n, hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL(mss_vote_kernel, dim3(1024), dim3(256), 0, stream, l.segs_out, l.grand + 3, d_cls, nof_labels, d_labels_out);
+    hipLaunchKernelGGL(mss_vote_kernel, dim3(1024), dim3(256), 0, stream, l.segs_out, l.grand + 3, d_cls, nof_labels, d_labels_out,
+                       (unsigned long long *)nullptr, (int32_t *)nullptr, (int64_t)0);
     DGRP_LAUNCH_CHECK();
     // the urun vector must outlive the asynchronous copy
     DGRP_HIP(hipStreamSynchronize(stream));

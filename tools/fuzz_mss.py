@@ -54,7 +54,7 @@ it = 0
 while time.time() < t_end:
     it += 1
     ml, xd = int(rng.choice([0, 1, 3, 10, 50])), int(rng.choice([-1, 0, 1, 10, 50]))
-    sub = int(rng.choice([0, 0, 1, 2, 7, 64, 500]))  # blocks per light unit (0: the built-in 2 048): state handed from unit to unit
+    sub = int(rng.choice([0, 0, 1, 2, 7, 64, 256, 500]))  # blocks per light unit (0: the built-in 2 048): state handed from unit to unit
     os.environ.pop("DGRP_MSS_SUB", None)
     if sub:
         os.environ["DGRP_MSS_SUB"] = str(sub)
