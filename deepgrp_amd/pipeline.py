@@ -157,12 +157,14 @@ class DeviceModel:
             pass
 
     # ---- model.predict_on_batch (prediction.py:106) ---------------------------------------
-    def forward_windows(self, d_idx: torch.Tensor, step: int, w0: int, nw: int) -> torch.Tensor:
-        """probs [nw, T, C] (device) of windows w0.. of a class-index tensor."""
+    def forward_windows(self, d_idx: torch.Tensor, step: int, w0: int, nw: int, handle=None) -> torch.Tensor:
+        """probs [nw, T, C] (device) of windows w0.. of a class-index tensor; `handle`: a view of this model with a precision
+        level of its own (ContigPipeline.handle) instead of the model's."""
+        h = handle if handle is not None else self.handle
         probs = torch.empty((nw, self.vecsize, self.classes), dtype=torch.float32, device=d_idx.device)
-        wb = lib().dgrp_forward_workspace_bytes(self.handle, nw)
+        wb = lib().dgrp_forward_workspace_bytes(h, nw)
         work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
-        check(lib().dgrp_forward_windows(self.handle, _ptr(d_idx), d_idx.numel(), step, w0, nw, _ptr(probs),
+        check(lib().dgrp_forward_windows(h, _ptr(d_idx), d_idx.numel(), step, w0, nw, _ptr(probs),
                                          _ptr(work), work.numel(), stream_ptr()), "dgrp_forward_windows")
         return probs
 

@@ -750,3 +750,13 @@ np.savez(out, **res)
     for k in whole.files:
         if not k.endswith("_chunk"):
             np.testing.assert_array_equal(whole[k], cut[k], err_msg=k)
+
+
+def test_graft_entry_smoke():
+    """__graft_entry__.smoke() itself (the driver runs it at round end): both precision levels, each checked through the pipeline's own
+    view of the model (a pipeline's level is a property of ITS handle, not of the model's)."""
+    import importlib
+    import sys
+    sys.path.insert(0, str(ROOT))
+    g = importlib.import_module("__graft_entry__")
+    g.smoke()
