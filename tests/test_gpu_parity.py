@@ -124,6 +124,8 @@ FORWARD_CASES = [
     (60, 342, True, 1.0, 50, 20), (64, 30, False, 2.0, 4, 50), (32, 50, True, 1.0, 5, 17),
     (96, 25, False, 1.0, 3, 35), (8, 20, True, 1.0, 2, 19), (100, 64, False, 1.5, 16, 16),
     (256, 60, False, 1.0, 25, 40), (256, 500, True, 1.5, 25, 19), (160, 40, True, 1.0, 9, 33), (200, 30, False, 2.0, 5, 17),
+    # gru_stream64_kernel: every count of 32-unit slices (5..8; odd: the last wave's second half is missing), each mode
+    (192, 50, True, 1.0, 10, 21), (224, 45, True, 2.0, 9, 18), (136, 64, False, 1.0, 8, 37), (250, 33, False, 1.5, 6, 16),
     # the reference's own model sizes (gru_units ~ qnormal(34, 5, 2), vecsize ~ qnormal(200, 20, 2), attention; notebooks/DeepGRP.ipynb:
     # 153-154) on gru_wave_kernel: every count of 16-unit groups, with and without attention, ragged window counts (the wave's two
     # row tiles of 8 windows: 1, 7, 8, 9, 15, 17 windows leave a tile empty, partly filled or the whole second group idle)
@@ -250,6 +252,9 @@ def test_predict_on_batch_keras_style(dev, orc):
                                                   # the row kernel's four-window workgroups across the partial-last-batch boundary
                                                   # (nwin % 4 != 0, nfull * B % 4 != 0: an idle fourth wave, the image's flush guard)
                                                   (1500, 100, 10, 7, 128, True), (1507, 100, 10, 5, 160, True), (1203, 90, 10, 9, 72, True),
+                                                  # gru_stream64_kernel's own merge (image, rows outside it, short last batch), 5..8 slices
+                                                  (2100, 120, 20, 6, 192, False), (1800, 90, 15, 4, 224, False), (1333, 80, 10, 3, 136, False),
+                                                  (2600, 500, 25, 7, 256, False),
                                                   # gru_wave_kernel: 16-window groups of two 8-window tiles, every image / no-image path
                                                   (2000, 200, 50, 7, 36, False), (2013, 200, 50, 5, 44, True), (1000, 60, 3, 11, 60, True),
                                                   (9000, 342, 50, 256, 60, True), (9000, 342, 50, 13, 48, False), (1700, 1500, 50, 3, 20, False),
