@@ -32,7 +32,8 @@ bash tools/sq_shape.sh r03/sq_u36 "u=36  T=200 s=50 attention" > /dev/null 2>&1
 bash tools/sq_shape.sh r03/sq_cfg5 "cfg5" > /dev/null 2>&1
 bash tools/sq_counters.sh r03/sq 50 > /dev/null 2>&1 || true
 echo "sq done" >> $out/progress.log
-DGRP_MSS_TRACE=1 python tools/mss_cliff.py 10 check 2>&1 | grep -v amdgpu.ids > $out/mss_cliff.txt
+MSS_CLIFF_TRACE=1 DGRP_MSS_TRACE=1 python tools/mss_cliff.py 10 check 2>&1 | grep -v amdgpu.ids > $out/mss_cliff.txt
 python tools/fp8_probe.py 50 4096 2>&1 | grep -v amdgpu.ids > $out/fp8_probe.txt
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o /tmp/l2_stream tools/ubench/l2_stream.hip > /dev/null 2>&1 && /tmp/l2_stream 200 > $out/l2_stream.txt 2>&1 || true
 python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --backend gloo --mbp 20 --steps 3 --warmup 1 --cpu-sample-bp 100000 > $out/bench_2ranks_one_gpu_gloo.json 2> $out/bench_2ranks.err || true
 echo "all done" >> $out/progress.log

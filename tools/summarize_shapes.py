@@ -46,7 +46,7 @@ for name, dst in (("sq_defaults", "wave_sq_counters_defaults_toml"), ("sq_u36", 
     p = os.path.join(src, name, "summary.txt")
     if os.path.exists(p):
         shutil.copyfile(p, os.path.join(out, f"{tag}_{dst}.txt"))
-for name in ("shapes.txt", "mss_cliff.txt", "fp8_probe.txt", "bench_2ranks_one_gpu_gloo.json"):
+for name in ("shapes.txt", "mss_cliff.txt", "fp8_probe.txt", "l2_stream.txt", "bench_2ranks_one_gpu_gloo.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copyfile(p, os.path.join(out, f"{tag}_{name}"))
