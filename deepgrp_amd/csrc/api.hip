@@ -239,7 +239,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     *out = nullptr;
     DGRP_REQUIRE(T >= 1 && T <= 65535, "dgrp_model_create: window size %d out of range", T);
     DGRP_REQUIRE(u >= 1 && u <= 2048, "dgrp_model_create: units=%d not supported (1..2048)", u);
-    DGRP_REQUIRE(C >= 2 && C <= 16, "dgrp_model_create: classes=%d not supported (2..16)", C);
+    DGRP_REQUIRE(C >= 2 && C <= DGRP_MAXC, "dgrp_model_create: classes=%d not supported (2..%d)", C, DGRP_MAXC);
     DGRP_REQUIRE(kernel && rec && bias && ffk && ffb && (!attention || scale), "dgrp_model_create: NULL tensor");
     char nm[8];
     int rc = dgrp_device_info(nm, sizeof(nm), nullptr, nullptr);
@@ -249,7 +249,7 @@ DGRP_EXPORT int dgrp_model_create(dgrp_model **out, int T, int u, int C, int att
     m->T = T; m->u = u; m->C = C; m->attention = attention ? 1 : 0;
     m->cell = 0;
     m->ref_only = 0; m->is_view = 0;
-    if (u > 256) return create_ref_only(out, m, kernel, rec, bias, 2 * 3 * (int64_t)u, ffk, (int64_t)(attention ? 2 : 1) * u * C, ffb,
+    if (u > 256 || C > 16) return create_ref_only(out, m, kernel, rec, bias, 2 * 3 * (int64_t)u, ffk, (int64_t)(attention ? 2 : 1) * u * C, ffb,
                                         attention ? scale : nullptr);
     m->UP = (u + 31) / 32 * 32;
     m->NW = m->UP / 32;
@@ -502,7 +502,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     *out = nullptr;
     DGRP_REQUIRE(T >= 1 && T <= 65535, "dgrp_model_create_lstm: window size %d out of range", T);
     DGRP_REQUIRE(u >= 1 && u <= 2048, "dgrp_model_create_lstm: units=%d not supported (1..2048)", u);
-    DGRP_REQUIRE(C >= 2 && C <= 16, "dgrp_model_create_lstm: classes=%d not supported (2..16)", C);
+    DGRP_REQUIRE(C >= 2 && C <= DGRP_MAXC, "dgrp_model_create_lstm: classes=%d not supported (2..%d)", C, DGRP_MAXC);
     DGRP_REQUIRE(kernel && rec && bias && ffk && ffb, "dgrp_model_create_lstm: NULL tensor");
     char nm[8];
     int rc = dgrp_device_info(nm, sizeof(nm), nullptr, nullptr);
@@ -510,7 +510,7 @@ DGRP_EXPORT int dgrp_model_create_lstm(dgrp_model **out, int T, int u, int C, co
     dgrp_model *m = new dgrp_model();
     m->T = T; m->u = u; m->C = C; m->attention = 0; m->cell = 1;
     m->ref_only = 0; m->is_view = 0;
-    if (u > 256) return create_ref_only(out, m, kernel, rec, bias, 4 * (int64_t)u, ffk, (int64_t)u * C, ffb, nullptr);
+    if (u > 256 || C > 16) return create_ref_only(out, m, kernel, rec, bias, 4 * (int64_t)u, ffk, (int64_t)u * C, ffb, nullptr);
     m->UP = (u + 31) / 32 * 32;
     m->NW = m->UP / 32;
     m->KS = m->UP / 16;

@@ -8,6 +8,8 @@
 #include "../../include/deepgrp_hip.h"
 
 #define DGRP_EXPORT extern "C" __attribute__((visibility("default")))
+// classes: the fused kernels lay the logits out as a 16-wide tile; up to DGRP_MAXC classes run on the plain-fp32 kernels (the labels are int8)
+#define DGRP_MAXC 64
 
 void dgrp_set_error(const char *fmt, ...);
 

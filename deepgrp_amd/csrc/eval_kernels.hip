@@ -3,15 +3,16 @@
 // Both are single-pass, HBM-bound byte scans (2 B/bp and 1-2 B/bp).
 #include "dgrp_common.h"
 
-// cnf[t][p] += 1 for every base: a 16 x 16 histogram per workgroup in LDS (wave-private copies would not pay: at
+// cnf[t][p] += 1 for every base: a 16 x 16 (beyond 16 classes: 64 x 64) histogram per workgroup in LDS (wave-private copies would not pay: at
 // most a few distinct cells are hot, ds_add_u32 serialises those whatever the layout), flushed with one 64-bit
 // atomic per non-zero cell.
 __global__ void __launch_bounds__(256) confusion_kernel(const int8_t *__restrict__ truth, const int8_t *__restrict__ pred,
                                                         int64_t n, int ncls, unsigned long long *__restrict__ cnf,
                                                         int *__restrict__ bad)
 {
-    __shared__ unsigned hist[256];
-    hist[threadIdx.x] = 0u;
+    __shared__ unsigned hist[DGRP_MAXC * DGRP_MAXC];
+    const int pitch = ncls <= 16 ? 16 : DGRP_MAXC;
+    for (int i = threadIdx.x; i < pitch * pitch; i += 256) hist[i] = 0u;
     __syncthreads();
     const int64_t per = 16 * 256;                                     // bases per workgroup iteration (16 B per lane)
     for (int64_t base = (int64_t)blockIdx.x * per; base < n; base += (int64_t)gridDim.x * per) {
@@ -22,28 +23,30 @@ __global__ void __launch_bounds__(256) confusion_kernel(const int8_t *__restrict
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int t = (int8_t)(tw[k >> 2] >> (8 * (k & 3))), q = (int8_t)(pw[k >> 2] >> (8 * (k & 3)));
-                if ((unsigned)t < (unsigned)ncls && (unsigned)q < (unsigned)ncls) atomicAdd(&hist[t * 16 + q], 1u);
+                if ((unsigned)t < (unsigned)ncls && (unsigned)q < (unsigned)ncls) atomicAdd(&hist[t * pitch + q], 1u);
                 else *bad = 1;
             }
         } else {
             for (int64_t i = i0; i < n && i < i0 + 16; ++i) {
                 const int t = truth[i], q = pred[i];
-                if ((unsigned)t < (unsigned)ncls && (unsigned)q < (unsigned)ncls) atomicAdd(&hist[t * 16 + q], 1u);
+                if ((unsigned)t < (unsigned)ncls && (unsigned)q < (unsigned)ncls) atomicAdd(&hist[t * pitch + q], 1u);
                 else *bad = 1;
             }
         }
     }
     __syncthreads();
-    const unsigned v = hist[threadIdx.x];
-    const int t = threadIdx.x >> 4, q = threadIdx.x & 15;
-    if (v != 0u && t < ncls && q < ncls) atomicAdd(&cnf[t * ncls + q], (unsigned long long)v);
+    for (int i = threadIdx.x; i < pitch * pitch; i += 256) {
+        const unsigned v = hist[i];
+        const int t = i / pitch, q = i % pitch;
+        if (v != 0u && t < ncls && q < ncls) atomicAdd(&cnf[t * ncls + q], (unsigned long long)v);
+    }
 }
 
 DGRP_EXPORT int dgrp_confusion_matrix(const int8_t *d_true, const int8_t *d_pred, int64_t n, int ncls, int64_t *d_cnf,
                                       int *d_bad, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    DGRP_REQUIRE(n >= 0 && ncls >= 1 && ncls <= 16 && d_cnf && d_bad, "dgrp_confusion_matrix: bad arguments (1 <= classes <= 16)");
+    DGRP_REQUIRE(n >= 0 && ncls >= 1 && ncls <= DGRP_MAXC && d_cnf && d_bad, "dgrp_confusion_matrix: bad arguments (1 <= classes <= 64)");
     DGRP_HIP(hipMemsetAsync(d_cnf, 0, sizeof(int64_t) * ncls * ncls, stream));
     DGRP_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), stream));
     if (n == 0) return DGRP_OK;

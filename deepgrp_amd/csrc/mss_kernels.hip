@@ -1242,25 +1242,27 @@ __global__ void __launch_bounds__(256) mss_vote_kernel(const int32_t *__restrict
             q = __shfl(q, 0);
             if ((int64_t)q < longcap) {
                 if (lane == 0) longlist[q] = (int32_t)sidx;
-                if (lane < 16) longlist[longcap + 16 * q + lane] = 0;
+                if (lane < DGRP_MAXC) longlist[longcap + DGRP_MAXC * q + lane] = 0;
                 continue;
             }
         }
-        int cnt[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) cnt[c] = 0;
-        for (int64_t j = st + lane; j < en; j += 64) {
-            const int l = cls[j];
-#pragma unroll
-            for (int c = 1; c < 16; ++c) cnt[c] += (l == c);
-        }
         int best = 1, bv = 0;
+        for (int c0 = 0; c0 < nof_labels; c0 += 16) {          // (16 classes per pass over the segment: one pass for the usual 5)
+            int cnt[16];
 #pragma unroll
-        for (int c = 1; c < 16; ++c) {
-            int v = cnt[c];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (c == 1) bv = v;
-            else if (c < nof_labels && bv < v) { best = c; bv = v; }
+            for (int c = 0; c < 16; ++c) cnt[c] = 0;
+            for (int64_t j = st + lane; j < en; j += 64) {
+                const int l = cls[j] - c0;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) cnt[c] += (l == c);
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                int v = cnt[c];
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                if (c0 + c == 1) bv = v;
+                else if (c0 + c > 1 && c0 + c < nof_labels && bv < v) { best = c0 + c; bv = v; }
+            }
         }
         for (int64_t j = st + lane; j < en; j += 64)
             if (cls[j] == 0) out[j] = (int8_t)best;
@@ -1278,35 +1280,37 @@ __global__ void __launch_bounds__(256) mss_vote_long_kernel(const int32_t *__res
     for (int64_t q = 0; q < nq; ++q) {
         const int64_t sidx = longlist[q];
         const int64_t st = segs[2 * sidx], en = segs[2 * sidx + 1];
-        int32_t *hist = longlist + longcap + 16 * q;
+        int32_t *hist = longlist + longcap + DGRP_MAXC * q;
         int best = 1;
         if (PHASE == 1) {
             int bv = hist[1];
-            for (int c = 2; c < nof_labels && c < 16; ++c)
+            for (int c = 2; c < nof_labels; ++c)
                 if (bv < hist[c]) { best = c; bv = hist[c]; }
         }
         for (int64_t c0 = st + (int64_t)blockIdx.x * MSS_VOTE_CHUNK; c0 < en; c0 += (int64_t)gridDim.x * MSS_VOTE_CHUNK) {
             const int64_t c1 = min(c0 + (int64_t)MSS_VOTE_CHUNK, en);
             if (PHASE == 0) {
-                __shared__ int sh[16];
-                if (threadIdx.x < 16) sh[threadIdx.x] = 0;
+                __shared__ int sh[DGRP_MAXC];
+                if (threadIdx.x < DGRP_MAXC) sh[threadIdx.x] = 0;
                 __syncthreads();
-                int cnt[16];
+                for (int b0 = 0; b0 < nof_labels; b0 += 16) {
+                    int cnt[16];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) cnt[c] = 0;
-                for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) {
-                    const int l = cls[j];
+                    for (int c = 0; c < 16; ++c) cnt[c] = 0;
+                    for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) {
+                        const int l = cls[j] - b0;
 #pragma unroll
-                    for (int c = 1; c < 16; ++c) cnt[c] += (l == c);
-                }
+                        for (int c = 0; c < 16; ++c) cnt[c] += (l == c);
+                    }
 #pragma unroll
-                for (int c = 1; c < 16; ++c) {
-                    int v = cnt[c];
-                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-                    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&sh[c], v);
+                    for (int c = 0; c < 16; ++c) {
+                        int v = cnt[c];
+                        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                        if ((threadIdx.x & 63) == 0 && v && b0 + c >= 1 && b0 + c < DGRP_MAXC) atomicAdd(&sh[b0 + c], v);
+                    }
                 }
                 __syncthreads();
-                if (threadIdx.x >= 1 && threadIdx.x < 16 && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
+                if (threadIdx.x >= 1 && threadIdx.x < DGRP_MAXC && sh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], sh[threadIdx.x]);
                 __syncthreads();
             } else {
                 for (int64_t j = c0 + threadIdx.x; j < c1; j += 256)
@@ -1319,7 +1323,7 @@ __global__ void __launch_bounds__(256) mss_vote_long_kernel(const int32_t *__res
 // A9 over the kept segments (l.segs_out, count in grand[3]); l.segs is free by now: the list of the long ones and their counters
 static int mss_vote_all(const mss_layout &l, const int8_t *d_cls, int nof_labels, int8_t *d_labels_out, int64_t n, hipStream_t stream)
 {
-    const int64_t longcap = n / MSS_VOTE_LONG + 1;                 // (17 longcap ints <= the 2 (n / 2 + 2) of l.segs)
+    const int64_t longcap = n / MSS_VOTE_LONG + 1;                 // ((1 + DGRP_MAXC) longcap ints <= the 2 (n / 2 + 2) of l.segs)
     unsigned long long *nlong = (unsigned long long *)l.grand;     // grand[0]: the scans are done with it
     DGRP_HIP(hipMemsetAsync(nlong, 0, 8, stream));
     hipLaunchKernelGGL(mss_vote_kernel, dim3(1024), dim3(256), 0, stream, l.segs_out, l.grand + 3, d_cls, nof_labels, d_labels_out, nlong,
@@ -1340,7 +1344,7 @@ DGRP_EXPORT int dgrp_mss_labels(const double *d_scores, const int8_t *d_cls, int
 {
     hipStream_t stream = (hipStream_t)stream_;
     DGRP_REQUIRE(n >= 0 && n < (1ll << 31), "dgrp_mss_labels: n=%lld out of range (the reference indexes with int)", (long long)n);
-    DGRP_REQUIRE(nof_labels >= 2 && nof_labels <= 16, "dgrp_mss_labels: nof_labels must be in 2..16");
+    DGRP_REQUIRE(nof_labels >= 2 && nof_labels <= DGRP_MAXC, "dgrp_mss_labels: nof_labels must be in 2..64");
     if (n == 0) {
         if (d_nseg) DGRP_HIP(hipMemsetAsync(d_nseg, 0, sizeof(int64_t), stream));
         return DGRP_OK;
@@ -1621,7 +1625,7 @@ DGRP_EXPORT int dgrp_mss_labels_batch(const double *d_scores, const int8_t *d_cl
 {
     hipStream_t stream = (hipStream_t)stream_;
     DGRP_REQUIRE(total_n >= 0 && total_n < (1ll << 31) && nrec >= 0 && (nrec == 0 || h_start), "dgrp_mss_labels_batch: bad arguments");
-    DGRP_REQUIRE(nof_labels >= 2 && nof_labels <= 16, "dgrp_mss_labels_batch: nof_labels must be in 2..16");
+    DGRP_REQUIRE(nof_labels >= 2 && nof_labels <= DGRP_MAXC, "dgrp_mss_labels_batch: nof_labels must be in 2..64");
     if (nrec == 0 || total_n == 0) return DGRP_OK;
     DGRP_REQUIRE(d_scores && d_cls && d_labels_out && d_work, "dgrp_mss_labels_batch: NULL pointer");
     DGRP_REQUIRE(h_start[0] == 0 && h_start[nrec] == total_n, "dgrp_mss_labels_batch: starts must run from 0 to total_n");

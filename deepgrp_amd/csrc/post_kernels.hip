@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) scores_kernel(const float *__restrict__ p
 
 DGRP_EXPORT int dgrp_scores(const float *d_probs, int64_t n, int C, double *d_scores, int8_t *d_cls, void *stream)
 {
-    DGRP_REQUIRE(n >= 0 && C >= 1 && C <= 16, "dgrp_scores: bad n/C");
+    DGRP_REQUIRE(n >= 0 && C >= 1 && C <= DGRP_MAXC, "dgrp_scores: bad n/C");
     if (n == 0) return DGRP_OK;
     DGRP_REQUIRE(d_probs && d_scores && d_cls, "dgrp_scores: NULL pointer");
     hipLaunchKernelGGL(scores_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, d_probs, n,
@@ -111,17 +111,17 @@ __global__ void __launch_bounds__(256) softmax_labels_kernel(const float *__rest
     for (int i = 0; i < nparts; ++i) gmax = fmaxf(gmax, part[i]);
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += nthreads) {
-        float e[16];
+        // (the exponentials twice -- a deterministic routine -- instead of an array of them: any number of classes in registers)
         float sum = 0.0f;
         for (int c = 0; c < C; ++c) {
-            e[c] = np_expf(a[i * C + c] - gmax);
-            sum = c == 0 ? e[0] : sum + e[c];                 // numpy folds a short row left to right
+            const float ec = np_expf(a[i * C + c] - gmax);
+            sum = c == 0 ? ec : sum + ec;                     // numpy folds a short row left to right
         }
         int best = 0;
-        float bv = __fdiv_rn(e[0], sum);
+        float bv = __fdiv_rn(np_expf(a[i * C] - gmax), sum);
         if (sm) sm[i * C] = bv;
         for (int c = 1; c < C; ++c) {
-            const float v = __fdiv_rn(e[c], sum);
+            const float v = __fdiv_rn(np_expf(a[i * C + c] - gmax), sum);
             if (sm) sm[i * C + c] = v;
             if (v > bv) { bv = v; best = c; }
         }
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) softmax_labels_kernel(const float *__rest
 DGRP_EXPORT int dgrp_softmax_labels(const float *d_probs, int64_t n, int C, float *d_softmax, int8_t *d_labels,
                                     void *d_work, int64_t work_bytes, void *stream)
 {
-    DGRP_REQUIRE(n >= 0 && C >= 1 && C <= 16, "dgrp_softmax_labels: bad n/C");
+    DGRP_REQUIRE(n >= 0 && C >= 1 && C <= DGRP_MAXC, "dgrp_softmax_labels: bad n/C");
     if (n == 0) return DGRP_OK;
     const int nparts = 1024;
     DGRP_REQUIRE(d_probs && d_labels && d_work && work_bytes >= (int64_t)(nparts * sizeof(float)),

@@ -145,12 +145,12 @@ __global__ void __launch_bounds__(256) ref_head_kernel(int T, int u, int C, int 
                                                        float *__restrict__ e, float *__restrict__ probs)
 {
     extern __shared__ float qc[];                            // q[u], ctx[u]
-    __shared__ float ctxlogit[16], scratch[4];
+    __shared__ float ctxlogit[DGRP_MAXC], scratch[4];
     float *const q = qc, *const ctx = qc + u;
     const int64_t w = blockIdx.x;
     const float *fwd = seq + (size_t)(w * 2) * T * u, *rev = fwd + (size_t)T * u;
     const int tid = threadIdx.x;
-    for (int c = tid; c < 16; c += 256) ctxlogit[c] = 0.0f;
+    for (int c = tid; c < DGRP_MAXC; c += 256) ctxlogit[c] = 0.0f;
     if (attention) {
         // AdditiveAttention with the averaged final states as the single query (deepgrp/model.py:309-319)
         for (int k = tid; k < u; k += 256) q[k] = 0.5f * (last[(size_t)(w * 2) * u + k] + last[(size_t)(w * 2 + 1) * u + k]);
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) ref_head_kernel(int T, int u, int C, int 
     __syncthreads();
     const float *wavg = ffk + (attention ? (size_t)u * C : 0);
     for (int t = tid; t < T; t += 256) {
-        float lg[16];
+        float lg[DGRP_MAXC];
         for (int c = 0; c < C; ++c) lg[c] = ffb[c] + ctxlogit[c];
         for (int k = 0; k < u; ++k) {
             const float a = 0.5f * (fwd[(size_t)t * u + k] + rev[(size_t)t * u + k]);

@@ -95,7 +95,8 @@ class DeviceModel:
         self.fp32_only = bool(lib().dgrp_model_flags(self.handle) & 4)
         if self.fp32_only:
             import warnings
-            warnings.warn(f"{self.rnn} with {self.units} units is beyond the fused kernels (256 units): every forward pass runs on the "
+            what = f"{self.units} units" if self.units > 256 else f"{self.classes} classes"
+            warnings.warn(f"{self.rnn} with {what} is beyond the fused kernels (256 units, 16 classes): every forward pass runs on the "
                           f"plain-fp32 kernels, tens of Mbp/s", RuntimeWarning, stacklevel=3)
 
     input_shape = property(lambda self: (None, self.vecsize, 5))

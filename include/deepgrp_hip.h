@@ -109,8 +109,8 @@ int dgrp_windows_onehot(const uint8_t *d_idx, int64_t n, int64_t T, int64_t s, i
  * Keras layout, gate columns z|r|h:  kernel [5,3u], recurrent [u,3u], bias [2,3u],
  * scale [u] or NULL (no attention), ff_kernel [(attention?2u:u), C], ff_bias [C].
  * Packs them into MFMA fragment order and uploads (synchronous).
- * Sizes: 1 <= u <= 2048, 2 <= C <= 16 (the reference's classes are len(repeats_to_search) + 1 = 5; its post-processing histograms
- * are laid out for up to 16 here), 1 <= T <= 65535.  Up to 256 units the fused kernels run; beyond, the model is created on the
+ * Sizes: 1 <= u <= 2048, 2 <= C <= 64 (the reference's classes are len(repeats_to_search) + 1 = 5; labels are int8), 1 <= T <= 65535.
+ * Up to 256 units and 16 classes the fused kernels run (their logit tile is 16 wide); beyond either, the model is created on the
  * "fp32 path" (dgrp_model_flags bit 2): every forward call goes through the plain-fp32 kernels of ref_kernels.hip, tens of Mbp/s --
  * the reference takes any `units` (deepgrp/model.py:117,219-229), so a large model is slow here, not refused. */
 int dgrp_model_create(dgrp_model **out, int T, int u, int C, int attention, const float *h_kernel,
@@ -267,7 +267,7 @@ int dgrp_predict_batch(const dgrp_model *m, const uint8_t *d_idx, int64_t nrec, 
 
 /* ---- N2: evaluation helpers of deepgrp.prediction on label arrays that are already in HBM.
  * deepgrp.prediction.confusion_matrix (deepgrp/prediction.py:204-222): d_cnf int64 [ncls, ncls] (zeroed here),
- * cnf[true, pred] += 1 per base; labels int8 in [0, ncls), ncls <= 16, arrays 16-byte aligned.  *d_bad (device
+ * cnf[true, pred] += 1 per base; labels int8 in [0, ncls), ncls <= 64, arrays 16-byte aligned.  *d_bad (device
  * int) is set to 1 if any label falls outside [0, ncls) -- the reference raises IndexError there. */
 int dgrp_confusion_matrix(const int8_t *d_true, const int8_t *d_pred, int64_t n, int ncls, int64_t *d_cnf,
                           int *d_bad, void *stream);

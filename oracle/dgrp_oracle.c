@@ -533,7 +533,7 @@ static const int ORC_COMP[5] = { 3, 2, 1, 0, 4 };
             }                                                                                    \
         }                                                                                        \
         for (int t = 0; t < T; ++t) {                                                            \
-            real_t lg[16], mx = -INFINITY, den = 0;                                              \
+            real_t lg[64], mx = -INFINITY, den = 0;                                              \
             for (int c = 0; c < C; ++c) {                                                        \
                 real_t acc = bd[c];                                                              \
                 if (attention) {                                                                 \
@@ -555,7 +555,7 @@ static const int ORC_COMP[5] = { 3, 2, 1, 0, 4 };
                      const real_t *scale, const real_t *Wd, const real_t *bd, real_t *probs,     \
                      int threads)                                                                \
     {                                                                                            \
-        if (C > 16) return -1;                                                                   \
+        if (C > 64) return -1;                                                                   \
         size_t wsz = (size_t)5 * u + (size_t)T * u + u + T;                                      \
         int nt = threads > 0 ? threads : 1;                                                      \
         real_t *work = (real_t *)malloc(sizeof(real_t) * wsz * (size_t)nt);                      \
@@ -622,7 +622,7 @@ ORC_NN_IMPL(orc_nn_forward_f64, double, exp, tanh)
             for (int k = 0; k < u; ++k) avg[(size_t)t * u + k] = (hf[k] + hr[k]) / 2;            \
         }                                                                                        \
         for (int t = 0; t < T; ++t) {                                                            \
-            real_t lg[16], mx = -INFINITY, den = 0;                                              \
+            real_t lg[64], mx = -INFINITY, den = 0;                                              \
             for (int c = 0; c < C; ++c) {                                                        \
                 real_t acc = bd[c];                                                              \
                 for (int k = 0; k < u; ++k) acc += avg[(size_t)t * u + k] * Wd[(size_t)k * C + c]; \
@@ -637,7 +637,7 @@ ORC_NN_IMPL(orc_nn_forward_f64, double, exp, tanh)
                      const real_t *Wx, const real_t *U, const real_t *bias, const real_t *Wd,    \
                      const real_t *bd, real_t *probs, int threads)                               \
     {                                                                                            \
-        if (C > 16) return -1;                                                                   \
+        if (C > 64) return -1;                                                                   \
         size_t wsz = (size_t)8 * u + (size_t)T * u;                                              \
         int nt = threads > 0 ? threads : 1;                                                      \
         real_t *work = (real_t *)malloc(sizeof(real_t) * wsz * (size_t)nt);                      \

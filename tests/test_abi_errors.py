@@ -39,7 +39,7 @@ CASES = [
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 0, 5, 0, P, P, P, P, P, None), "units"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 2049, 5, 0, P, P, P, P, P, None), "units"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 1, 0, P, P, P, P, P, None), "classes"),
-    ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 17, 0, P, P, P, P, P, None), "classes"),
+    ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 65, 0, P, P, P, P, P, None), "classes"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 5, 0, P, None, P, None, P, P), "NULL tensor"),
     ("dgrp_model_create", lambda: (C.pointer(C.c_void_p()), 200, 32, 5, 1, P, P, P, None, P, P), "NULL tensor"),   # attention without a scale
     ("dgrp_model_create_lstm", lambda: (None, 200, 32, 5, P, P, P, P, P), "NULL out"),
@@ -55,14 +55,14 @@ CASES = [
     ("dgrp_get_max", lambda: (None, 10, P, 2, 5, 5, 1, None), "NULL pointer"),
     ("dgrp_scores", lambda: (P, -1, 5, P, P, None), "bad n/C"),
     ("dgrp_scores", lambda: (P, 10, 0, P, P, None), "bad n/C"),
-    ("dgrp_scores", lambda: (P, 10, 17, P, P, None), "bad n/C"),
+    ("dgrp_scores", lambda: (P, 10, 65, P, P, None), "bad n/C"),
     ("dgrp_scores", lambda: (P, 10, 5, None, P, None), "NULL pointer"),
     ("dgrp_softmax_labels", lambda: (P, 10, 0, P, P, P, 1 << 20, None), "bad n/C"),
     ("dgrp_softmax_labels", lambda: (P, 10, 5, P, P, P, 16, None), "workspace"),
     ("dgrp_mss_labels", lambda: (P, P, -1, 5, 50, 50, P, None, P, 1 << 30, None), "out of range"),
     ("dgrp_mss_labels", lambda: (P, P, 1 << 31, 5, 50, 50, P, None, P, 1 << 30, None), "out of range"),
     ("dgrp_mss_labels", lambda: (P, P, 100, 1, 50, 50, P, None, P, 1 << 30, None), "nof_labels"),
-    ("dgrp_mss_labels", lambda: (P, P, 100, 17, 50, 50, P, None, P, 1 << 30, None), "nof_labels"),
+    ("dgrp_mss_labels", lambda: (P, P, 100, 65, 50, 50, P, None, P, 1 << 30, None), "nof_labels"),
     ("dgrp_mss_labels", lambda: (None, P, 100, 5, 50, 50, P, None, P, 1 << 30, None), "NULL pointer"),
     ("dgrp_mss_segments_host", lambda: (None, 0, None, 0, None), "NULL pointer"),
     ("dgrp_mss_labels_batch", lambda: (P, P, -1, 1, i64x1, 5, 50, 50, P, P, 1 << 30, None), "bad arguments"),
@@ -77,7 +77,7 @@ CASES = [
     ("dgrp_predict_record", lambda: (None, P, 1000, 50, 256, 50, 50, 1, 0, 0, P, 10, i64x1, P, 1 << 30, None), "bad arguments"),
     ("dgrp_predict_batch", lambda: (None, P, 1, P, P, P, P, 50, 256, 50, 50, P, 10, i64x1, P, 1 << 30, None), "bad arguments"),
     ("dgrp_confusion_matrix", lambda: (P, P, 10, 0, P, P, None), "classes"),
-    ("dgrp_confusion_matrix", lambda: (P, P, 10, 17, P, P, None), "classes"),
+    ("dgrp_confusion_matrix", lambda: (P, P, 10, 65, P, P, None), "classes"),
     ("dgrp_confusion_matrix", lambda: (P, P, -1, 5, P, P, None), "bad arguments"),
     ("dgrp_confusion_matrix", lambda: (P, P, 10, 5, None, P, None), "bad arguments"),
     ("dgrp_filter_segments", lambda: (P, P, -1, 50, None), "negative length"),

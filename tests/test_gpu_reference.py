@@ -204,6 +204,50 @@ def test_fp32_pipeline_vs_oracle(dev, orc, u, T, attention, use_mss, B):
     dm.close()
 
 
+@pytest.mark.parametrize("C_,attention,use_mss", [(20, True, True), (64, False, True), (33, False, False)])
+def test_many_classes_on_the_fp32_path(dev, orc, C_, attention, use_mss):
+    """More than 16 classes (the reference's label set is len(repeats_to_search) + 1, any length): the model is created on the fp32
+    path (a RuntimeWarning, flags bit 2) and the whole path holds: merged probabilities against the float64 statement, rows identical
+    to the post-processing of those probabilities (scores, MSS vote over all the labels or softmax labels, segments), the
+    confusion matrix with that many classes."""
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence
+    from deepgrp_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(C_)
+    u, T, B = 24, 60, 37
+    w = orc.Weights.random(u, C_, T, attention, seed=5, gain=3.0)
+    with pytest.warns(RuntimeWarning, match="classes"):
+        dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    assert dm.fp32_only and dm.classes == C_
+    body = "".join(rng.choice(list("ACGT"), size=9013))
+    seq = "NN" + body[:4000] + "N" * 120 + body[4000:]
+    pipe = ContigPipeline(dm, 50, B, 5, 50, use_mss)
+    st, d_idx = upload_sequence(seq.encode())
+    idx = d_idx.cpu().numpy()
+    nwin = orc.window_count(idx.size, T, 50)
+    merged = pipe.merged(d_idx).cpu().numpy()
+    want_merged = orc.predict_merged(idx, lambda a, b: orc.nn_forward(idx, w, 50, a, b, np.float64), T, C_, 50, B)
+    assert merged.shape == want_merged.shape and np.abs(merged - want_merged).max() < 5e-5
+    rows = pipe.run(seq, contig=3)
+    probs = dm.forward_windows(d_idx, 50, 0, nwin).cpu().numpy()
+    want = orc.predict_contig(seq, lambda _idx: (lambda a, b: probs[a:a + b]), T, C_, 50, B, 5, 50, use_mss)
+    got = np.stack([rows["start"], rows["end"], rows["label"]], 1).reshape(-1, 3)
+    np.testing.assert_array_equal(got, want)
+    assert len(got) > 20 and len(set(got[:, 2].tolist())) > 5                      # many labels really occur
+    # confusion matrix with C_ classes
+    import torch
+    a = rng.integers(0, C_, size=5003).astype(np.int8)
+    b = rng.integers(0, C_, size=5003).astype(np.int8)
+    d_a, d_b = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    cnf = torch.zeros((C_, C_), dtype=torch.int64, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    assert L.dgrp_confusion_matrix(d_a.data_ptr(), d_b.data_ptr(), a.size, C_, cnf.data_ptr(), bad.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(cnf.cpu().numpy(), np.histogram2d(a, b, bins=(np.arange(C_ + 1), np.arange(C_ + 1)))[0].astype(np.int64))
+    assert int(bad.item()) == 0
+    dm.close()
+
+
 def test_cli_precise(tmp_path, orc):
     rng = np.random.default_rng(8)
     fa = tmp_path / "p.fa"
