@@ -138,25 +138,52 @@ def sharded_file_leg(args, rank, world, raw, weights, n_bases, dist, torch):
     record gather -> rank 0 writes the TSV.  Timed between barriers on the second of two runs."""
     from deepgrp_amd import fasta as dgfasta, model as dgmodel
     from deepgrp_amd.__main__ import CommandLineParser, main as cli_main
-    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    # room for every rank's part and the joined file (a container's /dev/shm may be 64 MB): decided together, so that no rank is left
+    # waiting in a barrier for one that could not write
+    need = (2 * world + 1) * (len(raw) + len(raw) // 60 + 4096)
+    def room(d):
+        try:
+            st = os.statvfs(d)
+            return os.path.isdir(d) and os.access(d, os.W_OK) and st.f_bavail * st.f_frsize > need
+        except OSError:
+            return False
+    choice = [None] * world
+    dist.all_gather_object(choice, "/dev/shm" if room("/dev/shm") else "/tmp" if room("/tmp") else "")
+    if any(c != choice[0] for c in choice) or not choice[0]:
+        return {"skipped": f"no directory with {need >> 20} MB free on every rank (/dev/shm, /tmp)"} if rank == 0 else None
+    shm = choice[0]
     tag = os.environ.get("MASTER_PORT", "0")
     part = os.path.join(shm, f"dgrp_bench_{tag}_part{rank}.fa")
     fa_path = os.path.join(shm, f"dgrp_bench_{tag}_all.fa")
     mpath = os.path.join(shm, f"dgrp_bench_{tag}_model.hdf5")
     tsv = os.path.join(shm, f"dgrp_bench_{tag}_out.tsv")
+    def together(err):                                       # an I/O error on one rank reaches every rank (then: leg skipped)
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        return next((e for e in errs if e), None)
     try:
-        write_fasta(part, b"chr_rank%d" % rank, raw)
-        dist.barrier()
-        if rank == 0:
-            import shutil
-            with open(fa_path, "wb") as dst:
-                for r in range(world):
-                    with open(os.path.join(shm, f"dgrp_bench_{tag}_part{r}.fa"), "rb") as src:
-                        shutil.copyfileobj(src, dst, 16 << 20)
-            dgmodel.save_keras_hdf5(mpath, weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
-                                    weights["ff_bias"], weights["scale"], vecsize=T)
-        dist.barrier()
-        os.unlink(part)
+        err = None
+        try:
+            write_fasta(part, b"chr_rank%d" % rank, raw)
+        except OSError as e:
+            err = f"rank {rank}: {e}"
+        err = together(err)
+        if err is None and rank == 0:
+            try:
+                import shutil
+                with open(fa_path, "wb") as dst:
+                    for r in range(world):
+                        with open(os.path.join(shm, f"dgrp_bench_{tag}_part{r}.fa"), "rb") as src:
+                            shutil.copyfileobj(src, dst, 16 << 20)
+                dgmodel.save_keras_hdf5(mpath, weights["kernel"], weights["recurrent_kernel"], weights["bias"], weights["ff_kernel"],
+                                        weights["ff_bias"], weights["scale"], vecsize=T)
+            except OSError as e:
+                err = f"rank 0: {e}"
+        err = together(err)
+        if os.path.exists(part):
+            os.unlink(part)
+        if err is not None:
+            return {"skipped": err} if rank == 0 else None
         argv = ["-b", str(BATCH), "-s", str(STEP), "-x", str(XDROP), "-l", str(MIN_MSS), "predict", mpath, fa_path, "--output", tsv]
         if args.fast:
             argv.append("--fast")
