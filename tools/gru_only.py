@@ -9,7 +9,7 @@ from deepgrp_amd.pipeline import ContigPipeline, DeviceModel, upload_sequence
 mbp = float(sys.argv[1]) if len(sys.argv) > 1 else 50
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 if len(sys.argv) > 3 and sys.argv[3] == "lstm":
-    rng = np.random.default_rng(0); u = 128
+    rng = np.random.default_rng(0); u = int(os.environ.get("LSTM_U", "128"))
     q = np.linalg.qr(rng.normal(size=(4 * u, u)))[0].T
     m = DeviceModel(rng.uniform(-.1, .1, (5, 4 * u)), q, rng.normal(0, .05, 4 * u), rng.uniform(-.2, .2, (u, 5)), np.zeros(5), None, 200, rnn="LSTM")
     FL = 16 * u * u * 200 + 2 * u * 5 * 200
