@@ -47,6 +47,8 @@ _SIGNATURES = {
     "dgrp_forward_window_chunk": (i64, [vp]),
     "dgrp_forward_windows": (cint, [vp, vp, i64, i64, i64, i64, vp, vp, i64, vp]),
     "dgrp_forward_merge": (cint, [vp, vp, i64, i64, i64, i64, i64, vp, vp, i64, vp]),
+    "dgrp_forward_merge_record": (cint, [vp, vp, i64, i64, i64, vp, vp, i64, vp]),
+    "dgrp_forward_merge_record_workspace_bytes": (i64, [vp, i64, i64]),
     "dgrp_forward_reference_workspace_bytes": (i64, [vp, i64]),
     "dgrp_forward_windows_reference": (cint, [vp, vp, i64, i64, i64, i64, vp, vp, i64, vp]),
     "dgrp_get_max": (cint, [vp, i64, vp, i64, i64, i64, i64, vp]),

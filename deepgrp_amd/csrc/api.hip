@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <vector>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -752,6 +753,111 @@ DGRP_EXPORT int64_t dgrp_forward_window_chunk(const dgrp_model *m)
     return m ? record_window_chunk(m) : 0;
 }
 
+// ---- lanes: the chunks of an attention model's record alternate between DGRP_LANES internal streams ------------------------------
+// The recurrent pre-pass is bound by the matrix cores and the vector unit and moves little memory; the second kernel is bound by HBM
+// and leaves the CUs it sits on mostly waiting.  Chunk after chunk on ONE stream the two never meet; on lanes the second kernel of
+// one chunk runs beside the pre-pass of the next (r03, tools/two_stream_probe.py: the reference's default model +4.5 %, its
+// hyper-parameter space +6.5 %, 128 units and more +1 %: those stay on one stream).  The merged output is a max: the order in
+// which chunks land does not matter, bit for bit.  Each lane has a spill of its own, a third of the one-stream chunk.
+#define DGRP_LANES 3
+static int64_t lane_window_chunk(const dgrp_model *m)            // 0: one stream
+{
+    if (m->ref_only || !m->attention) return 0;
+    if (const char *e = getenv("DGRP_LANE_CHUNK")) {            // tests: lanes on tiny records
+        const long long v = atoll(e);
+        return v >= 16 ? (int64_t)(v / 16 * 16) : 0;
+    }
+    const int64_t c = record_window_chunk(m);
+    if (c < 65536) return 0;
+    const int64_t lc = c / DGRP_LANES / 32768 * 32768;
+    return lc >= 32768 ? lc : 32768;
+}
+struct lane_pool { hipStream_t s[DGRP_LANES]; int dev; bool ok; };
+static lane_pool *lanes_get()
+{
+    static std::mutex mu;
+    static std::vector<lane_pool *> pools;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    for (lane_pool *q : pools)
+        if (q->dev == dev) return q->ok ? q : nullptr;
+    lane_pool *q = new lane_pool();
+    q->dev = dev; q->ok = true;
+    for (int i = 0; i < DGRP_LANES; ++i)
+        if (hipStreamCreateWithFlags(&q->s[i], hipStreamNonBlocking) != hipSuccess) q->ok = false;
+    pools.push_back(q);
+    return q->ok ? q : nullptr;
+}
+
+// workspace of dgrp_forward_merge_record: one forward workspace per lane (or the one of a whole chunk)
+static int64_t record_forward_bytes(const dgrp_model *m, int64_t nwin)
+{
+    const int64_t lc = lane_window_chunk(m);
+    if (lc > 0 && nwin > lc)
+        return DGRP_LANES * dgrp_align_up(std::max<int64_t>(dgrp_forward_workspace_bytes(m, std::min(lc, nwin)), 256), 256);
+    const int64_t chunk = std::min<int64_t>(record_window_chunk(m), nwin > 0 ? nwin : 1);
+    return std::max<int64_t>(dgrp_forward_workspace_bytes(m, chunk), 256);
+}
+
+DGRP_EXPORT int64_t dgrp_forward_merge_record_workspace_bytes(const dgrp_model *m, int64_t n, int64_t s)
+{
+    if (!m || n < 0 || s < 1) return 0;
+    return record_forward_bytes(m, dgrp_window_count(n, m->T, s));
+}
+
+// prediction.py:89-111 for a whole record: every window, chunk by chunk, max-merged into d_out [n, C] (which the caller has zeroed)
+DGRP_EXPORT int dgrp_forward_merge_record(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch, float *d_out,
+                                          void *d_work, int64_t work_bytes, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    DGRP_REQUIRE(m && n >= 0 && s >= 1 && batch >= 1, "dgrp_forward_merge_record: bad arguments");
+    const int64_t nwin = dgrp_window_count(n, m->T, s);
+    if (nwin == 0) return DGRP_OK;
+    DGRP_REQUIRE(d_idx && d_out && d_work, "dgrp_forward_merge_record: NULL pointer");
+    const int64_t need = record_forward_bytes(m, nwin);
+    if (work_bytes < need) {
+        dgrp_set_error("dgrp_forward_merge_record: workspace %lld < %lld bytes", (long long)work_bytes, (long long)need);
+        return DGRP_ENOMEM;
+    }
+    const int64_t lc = lane_window_chunk(m);
+    lane_pool *lp = lc > 0 && nwin > lc ? lanes_get() : nullptr;
+    if (!lp) {
+        const int64_t chunk = lc > 0 && nwin > lc ? lc : record_window_chunk(m);      // (no lanes to be had: their chunk, one stream)
+        for (int64_t w0 = 0; w0 < nwin; w0 += chunk) {
+            const int64_t nw = std::min<int64_t>(chunk, nwin - w0);
+            const int rc = dgrp_forward_merge(m, d_idx, n, s, batch, w0, nw, d_out, d_work, work_bytes, stream);
+            if (rc) return rc;
+        }
+        return DGRP_OK;
+    }
+    const int64_t per = need / DGRP_LANES;
+    hipEvent_t fork = nullptr, join[DGRP_LANES] = { nullptr, nullptr, nullptr };
+    int rc = DGRP_OK;
+    auto bail = [&](hipError_t e) { if (e != hipSuccess && rc == DGRP_OK) { dgrp_set_error("dgrp_forward_merge_record: %s", hipGetErrorString(e)); rc = DGRP_EHIP; } };
+    bail(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+    for (int i = 0; i < DGRP_LANES; ++i) bail(hipEventCreateWithFlags(&join[i], hipEventDisableTiming));
+    if (rc == DGRP_OK) {
+        bail(hipEventRecord(fork, stream));                       // the lanes start behind what the caller's stream holds (the zeroed output)
+        for (int i = 0; i < DGRP_LANES; ++i) bail(hipStreamWaitEvent(lp->s[i], fork, 0));
+        int64_t k = 0;
+        for (int64_t w0 = 0; w0 < nwin && rc == DGRP_OK; w0 += lc, ++k) {
+            const int64_t nw = std::min<int64_t>(lc, nwin - w0);
+            const int lane = (int)(k % DGRP_LANES);
+            rc = dgrp_forward_merge(m, d_idx, n, s, batch, w0, nw, d_out, (char *)d_work + lane * per, per, lp->s[lane]);
+        }
+        // join: the caller's stream goes on behind every lane (also after an error: nothing may still run when the caller frees)
+        for (int i = 0; i < DGRP_LANES; ++i) {
+            bail(hipEventRecord(join[i], lp->s[i]));
+            bail(hipStreamWaitEvent(stream, join[i], 0));
+        }
+    }
+    if (fork) (void)hipEventDestroy(fork);
+    for (int i = 0; i < DGRP_LANES; ++i)
+        if (join[i]) (void)hipEventDestroy(join[i]);
+    return rc;
+}
+
 struct record_layout {
     int64_t out, scores, cls, labels, count, fwd, post, bytes, post_bytes, fwd_bytes;
 };
@@ -762,13 +868,12 @@ static record_layout record_carve(const dgrp_model *m, int64_t n, int64_t s, int
     int64_t p = 0;
     auto take = [&](int64_t b) { const int64_t q = p; p += dgrp_align_up(b, 256); return q; };
     const int64_t nwin = dgrp_window_count(n, m->T, s);
-    const int64_t chunk = std::min<int64_t>(record_window_chunk(m), nwin > 0 ? nwin : 1);
     l.out = take(n * m->C * 4);
     l.scores = take(use_mss ? n * 8 : 0);
     l.cls = take(use_mss ? n : 0);
     l.labels = take(n);
     l.count = take(8);
-    l.fwd_bytes = std::max<int64_t>(dgrp_forward_workspace_bytes(m, chunk), 256);
+    l.fwd_bytes = record_forward_bytes(m, nwin);
     l.fwd = take(l.fwd_bytes);
     l.post_bytes = std::max<int64_t>(std::max<int64_t>(use_mss ? dgrp_mss_workspace_bytes(n) : 4096, dgrp_segments_workspace_bytes(n)), 4096);
     l.post = take(l.post_bytes);
@@ -802,14 +907,8 @@ DGRP_EXPORT int dgrp_predict_record(const dgrp_model *m, const uint8_t *d_idx, i
     int8_t *labels = (int8_t *)(w + l.labels);
     int64_t *d_count = (int64_t *)(w + l.count);
     DGRP_HIP(hipMemsetAsync(out, 0, (size_t)n * m->C * 4, stream));                    // np.zeros, prediction.py:103
-    const int64_t nwin = dgrp_window_count(n, m->T, s);
-    const int64_t chunk = record_window_chunk(m);
-    for (int64_t w0 = 0; w0 < nwin; w0 += chunk) {
-        const int64_t nw = std::min<int64_t>(chunk, nwin - w0);
-        int rc = dgrp_forward_merge(m, d_idx, n, s, batch, w0, nw, out, w + l.fwd, l.fwd_bytes, stream);
-        if (rc) return rc;
-    }
-    int rc;
+    int rc = dgrp_forward_merge_record(m, d_idx, n, s, batch, out, w + l.fwd, l.fwd_bytes, stream);
+    if (rc) return rc;
     if (use_mss) {
         rc = dgrp_scores(out, n, m->C, (double *)(w + l.scores), (int8_t *)(w + l.cls), stream);
         if (rc) return rc;

@@ -332,6 +332,13 @@ class ContigPipeline:
                     i += 1
                 w0 += nw
             return out
+        if self.event_log is None and self.chunk_windows >= (1 << 20):
+            # the library's own loop over the record (attention models with small spills: chunks alternating between its lanes)
+            wb = L.dgrp_forward_merge_record_workspace_bytes(self.handle, n, self.step)
+            work = torch.empty(max(wb, 256), dtype=torch.uint8, device=d_idx.device)
+            check(L.dgrp_forward_merge_record(self.handle, _ptr(d_idx), n, self.step, self.batch, _ptr(out), _ptr(work), work.numel(),
+                                              stream_ptr()), "dgrp_forward_merge_record")
+            return out
         chunk = max(16, min(self.chunk_windows, L.dgrp_forward_window_chunk(self.handle)))     # attention: the avg[t] spill bounds a launch
         work = None
         w0 = 0

@@ -173,6 +173,15 @@ int dgrp_forward_merge(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int
                        int64_t batch, int64_t w0, int64_t nw, float *d_out, void *d_work,
                        int64_t work_bytes, void *stream);
 
+/* prediction.py:89-111 for a WHOLE record: every window, chunk by chunk (dgrp_forward_window_chunk), max-merged into d_out [n, C],
+ * which the caller has zeroed.  Attention models whose chunk is at least 65 536 windows (up to 64 units at the usual window sizes)
+ * alternate the chunks between three internal streams ("lanes"), each with a spill of its own: the second kernel of one chunk --
+ * HBM-bound -- runs beside the recurrent pre-pass of the next; the caller's stream is forked in front of the first chunk and joined
+ * behind the last.  A max-merge: the result does not depend on the order, bit for bit.  dgrp_predict_record runs this. */
+int64_t dgrp_forward_merge_record_workspace_bytes(const dgrp_model *m, int64_t n, int64_t s);
+int dgrp_forward_merge_record(const dgrp_model *m, const uint8_t *d_idx, int64_t n, int64_t s, int64_t batch, float *d_out,
+                              void *d_work, int64_t work_bytes, void *stream);
+
 /* Accuracy yardstick (an addition; no counterpart in the reference, whose TensorFlow graph IS fp32): the same windows
  * through a plain fp32 evaluation of deepgrp/model.py:293-336 on the device -- fp32 weights and state, expf/tanhf, no
  * fp16, no MFMA -- so that the deviation of the fp16-operand fused kernel can be measured on the caller's own weights

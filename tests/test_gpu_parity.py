@@ -504,6 +504,36 @@ def test_mss_stitched_pieces(L, dev, orc, drift, exact, xd, monkeypatch, capfd):
         assert "parts (" in err and "not stitched" not in err, err        # the upward drift is the case this path exists for
 
 
+@pytest.mark.parametrize("u,T,s,B,N,lane", [(36, 60, 10, 7, 9001, 64), (60, 100, 25, 256, 20011, 160), (20, 40, 5, 5, 3003, 16)])
+def test_lanes_merge_identical(dev, orc, L, u, T, s, B, N, lane, monkeypatch):
+    """dgrp_forward_merge_record on lanes (the chunks of an attention model's record alternating between three internal streams,
+    forced here by a tiny lane chunk): the merged array is bit for bit the one of the chunks in order on one stream, and the record
+    path built on it gives the oracle's rows."""
+    from deepgrp_amd.pipeline import ContigPipeline, DeviceModel
+    rng = np.random.default_rng(u + lane)
+    w = orc.Weights.random(u, 5, T, True, seed=9, gain=2.0)
+    dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    idx = _seq_idx(rng, N)
+    d_idx = _t(idx, dev)
+    pipe = ContigPipeline(dm, s, B, 3, 10, True)
+    monkeypatch.delenv("DGRP_LANE_CHUNK", raising=False)
+    one = pipe.merged(d_idx).cpu().numpy()
+    rows_one = pipe.run_idx(d_idx, 5, contig=2)
+    monkeypatch.setenv("DGRP_LANE_CHUNK", str(lane))
+    nwin = orc.window_count(N, T, s)
+    assert nwin > 3 * lane                                                # every lane gets more than one chunk
+    assert L.dgrp_forward_merge_record_workspace_bytes(pipe.handle, N, s) >= 3 * L.dgrp_forward_workspace_bytes(pipe.handle, lane)
+    for _ in range(3):
+        lanes = pipe.merged(d_idx).cpu().numpy()
+        np.testing.assert_array_equal(lanes.view(np.uint32), one.view(np.uint32))
+    rows_lanes = pipe.run_idx(d_idx, 5, contig=2)
+    np.testing.assert_array_equal(rows_lanes, rows_one)
+    probs = dm.forward_windows(d_idx, s, 0, nwin).cpu().numpy()
+    want = orc.merge_all(probs, N, s, B)
+    np.testing.assert_array_equal(lanes.view(np.uint32), want.view(np.uint32))
+    dm.close()
+
+
 def test_softmax_path_golden(L, dev):
     g = golden("softmax.npz")
     probs = g["probs"]
