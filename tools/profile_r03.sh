@@ -14,7 +14,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/prof_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/prof_write -- python3 $B50 > $out/prof_write.log 2>&1
 echo "bench passes done" >> $out/progress.log
 # model shapes of the reference (defaults.toml, its hyper-parameter space) and BASELINE configs[4]: kernel times + HBM bytes per kernel
-export SHAPES_SPLIT_ONLY=1
+# (per-kernel passes with the library's lanes off -- DGRP_LANE_CHUNK=0: one stream, every kernel alone on the chip; shapes.txt below is
+# the product path, lanes and all)
+export SHAPES_SPLIT_ONLY=1 DGRP_LANE_CHUNK=0
 i=0
 for shape in "defaults.toml" "u=36  T=200 s=50 attention" "u=128 T=200 s=50 attention" "cfg5"; do
     i=$((i + 1))
@@ -24,13 +26,15 @@ for shape in "defaults.toml" "u=36  T=200 s=50 attention" "u=128 T=200 s=50 atte
     echo "$shape" > $out/shape${i}_name.txt
     echo "shape $i done" >> $out/progress.log
 done
-unset SHAPES_SPLIT_ONLY
+unset SHAPES_SPLIT_ONLY DGRP_LANE_CHUNK
 python tools/bench_shapes.py 2>&1 | grep -v amdgpu.ids > $out/shapes.txt
 echo "shapes done" >> $out/progress.log
+export DGRP_LANE_CHUNK=0
 bash tools/sq_shape.sh r03/sq_defaults "defaults.toml" > /dev/null 2>&1
 bash tools/sq_shape.sh r03/sq_u36 "u=36  T=200 s=50 attention" > /dev/null 2>&1
 bash tools/sq_shape.sh r03/sq_cfg5 "cfg5" > /dev/null 2>&1
 bash tools/sq_counters.sh r03/sq 50 > /dev/null 2>&1 || true
+unset DGRP_LANE_CHUNK
 echo "sq done" >> $out/progress.log
 MSS_CLIFF_TRACE=1 DGRP_MSS_TRACE=1 python tools/mss_cliff.py 10 check 2>&1 | grep -v amdgpu.ids > $out/mss_cliff.txt
 python tools/fp8_probe.py 50 4096 2>&1 | grep -v amdgpu.ids > $out/fp8_probe.txt

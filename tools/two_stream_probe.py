@@ -41,11 +41,11 @@ def run(nstreams, chunk):
 
 
 full = int(L.dgrp_forward_window_chunk(h))
-for chunk in (full, full // 2, 32768, 16384):
-    chunk = max(16384, chunk // 16384 * 16384)
-    a, ra = min((run(1, chunk) for _ in range(3)), key=lambda x: x[0])
-    b, rb = min((run(2, chunk) for _ in range(3)), key=lambda x: x[0])
-    c, rc = min((run(3, chunk) for _ in range(3)), key=lambda x: x[0])
-    same = bool(torch.equal(ra, rb)) and bool(torch.equal(ra, rc))
-    print(f"u={u} T={T} {mbp:g} Mbp, chunks of {chunk} windows: one stream {a:.1f} ms ({mbp * 1e3 / a:.0f} Mbp/s), two {b:.1f} ms ({mbp * 1e3 / b:.0f}), "
-          f"three {c:.1f} ms ({mbp * 1e3 / c:.0f}); merged arrays identical: {same}", flush=True)
+os.environ["DGRP_LANE_CHUNK"] = "0"                   # the library's own lanes off: this probe makes its own
+run(1, full)                                          # (warm the allocator: the first run of a size pays for its workspaces)
+for chunk in (full, 32768, 16384, 8192):
+    chunk = max(8192, chunk // 8192 * 8192)
+    res = [min((run(k, chunk) for _ in range(3)), key=lambda x: x[0]) for k in (1, 2, 3, 4, 6)]
+    same = all(bool(torch.equal(res[0][1], r[1])) for r in res[1:])
+    print(f"u={u} T={T} {mbp:g} Mbp, chunks of {chunk} windows: " + ", ".join(f"{k} stream(s) {r[0]:.1f} ms ({mbp * 1e3 / r[0]:.0f} Mbp/s)"
+          for k, r in zip((1, 2, 3, 4, 6), res)) + f"; merged arrays identical: {same}", flush=True)
