@@ -737,7 +737,9 @@ static int64_t spill_cap_bytes()
 static int64_t record_window_chunk(const dgrp_model *m)
 {
     if (m->ref_only) return ref_sub_windows(m);
-    if (!m->attention) return 1ll << 20;
+    // no spill bounds a launch: 8 M windows at a time (a 250 Mbp chromosome in ONE launch: 5 launches of 2^20 windows each ended in a
+    // round of workgroups that filled a fraction of the chip: +0.8 % on the benchmark record)
+    if (!m->attention) return 1ll << 23;
     // whole rounds of workgroups where possible: 32 768 windows = 256 CUs x 8 workgroups x 16 windows is a whole number of rounds
     // for every recurrent kernel (8, 4, 2 or 1 workgroups of 16 windows, or one of 32, per CU); below that 4096 = 256 CUs x 16
     // (a launch of 4112 windows costs a large model two rounds for the work of one)

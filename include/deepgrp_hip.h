@@ -152,7 +152,7 @@ int dgrp_model_view(const dgrp_model *m, int level, dgrp_model **out);
 int64_t dgrp_forward_workspace_bytes(const dgrp_model *m, int64_t nw);
 /* Windows per call the library itself uses inside dgrp_predict_record, and the size callers of dgrp_forward_merge should cut a
  * record into (the reference's predict loop, deepgrp/prediction.py:104-110, goes batch by batch; here a "batch" is a launch):
- * 2^20 without attention; with attention as many as keep the avg[t] spill of one launch within 1/32 of the card's memory, at most
+ * 2^23 without attention (a 250 Mbp chromosome at stride 50 in one launch); with attention as many as keep the avg[t] spill of one launch within 1/32 of the card's memory, at most
  * 8 GiB (environment DGRP_SPILL_BYTES overrides), in multiples of 32 768 windows (whole rounds of workgroups for every recurrent
  * kernel) or, below that, of 4096.  0 for a null model. */
 int64_t dgrp_forward_window_chunk(const dgrp_model *m);

@@ -702,7 +702,7 @@ def test_forward_window_chunk(orc):
         dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
         c = L.dgrp_forward_window_chunk(dm.handle)
         if not att:
-            assert c == 1 << 20
+            assert c == 1 << 23
         else:
             per = T * ((u + 31) // 32 * 32 * 4 + 5 * 4)
             assert 4096 <= c <= 1 << 20 and c * per <= 8 << 30 and (c + 4096) * per > (8 << 30) // 8
