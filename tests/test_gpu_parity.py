@@ -515,22 +515,24 @@ def test_lanes_merge_identical(dev, orc, L, u, T, s, B, N, lane, monkeypatch):
     dm = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
     idx = _seq_idx(rng, N)
     d_idx = _t(idx, dev)
-    pipe = ContigPipeline(dm, s, B, 3, 10, True)
-    monkeypatch.delenv("DGRP_LANE_CHUNK", raising=False)
-    one = pipe.merged(d_idx).cpu().numpy()
-    rows_one = pipe.run_idx(d_idx, 5, contig=2)
-    monkeypatch.setenv("DGRP_LANE_CHUNK", str(lane))
     nwin = orc.window_count(N, T, s)
     assert nwin > 3 * lane                                                # every lane gets more than one chunk
-    assert L.dgrp_forward_merge_record_workspace_bytes(pipe.handle, N, s) >= 3 * L.dgrp_forward_workspace_bytes(pipe.handle, lane)
-    for _ in range(3):
-        lanes = pipe.merged(d_idx).cpu().numpy()
-        np.testing.assert_array_equal(lanes.view(np.uint32), one.view(np.uint32))
-    rows_lanes = pipe.run_idx(d_idx, 5, contig=2)
-    np.testing.assert_array_equal(rows_lanes, rows_one)
-    probs = dm.forward_windows(d_idx, s, 0, nwin).cpu().numpy()
-    want = orc.merge_all(probs, N, s, B)
-    np.testing.assert_array_equal(lanes.view(np.uint32), want.view(np.uint32))
+    for fast in (False, True):                                            # float32 spill / fp16 spill
+        pipe = ContigPipeline(dm, s, B, 3, 10, True, fast=fast)
+        monkeypatch.delenv("DGRP_LANE_CHUNK", raising=False)
+        one = pipe.merged(d_idx).cpu().numpy()
+        rows_one = pipe.run_idx(d_idx, 5, contig=2)
+        monkeypatch.setenv("DGRP_LANE_CHUNK", str(lane))
+        assert L.dgrp_forward_merge_record_workspace_bytes(pipe.handle, N, s) >= 3 * L.dgrp_forward_workspace_bytes(pipe.handle, lane)
+        for _ in range(3):
+            lanes = pipe.merged(d_idx).cpu().numpy()
+            np.testing.assert_array_equal(lanes.view(np.uint32), one.view(np.uint32))
+        rows_lanes = pipe.run_idx(d_idx, 5, contig=2)
+        np.testing.assert_array_equal(rows_lanes, rows_one)
+        probs = dm.forward_windows(d_idx, s, 0, nwin, handle=pipe.handle).cpu().numpy()
+        want = orc.merge_all(probs, N, s, B)
+        np.testing.assert_array_equal(lanes.view(np.uint32), want.view(np.uint32))
+        pipe.close()
     dm.close()
 
 
