@@ -650,7 +650,7 @@ def test_predict_record_equals_staged_path(orc, kind):
     m.close()
 
 
-def test_cli_console_forms_and_npz_input(tmp_path):
+def test_cli_console_forms_and_npz_input(tmp_path, orc):
     """The `deepgrp` console script's callable (pyproject.toml) in the README form `deepgrp <model> <fasta>` and in the
     reference's form `deepgrp [flags] predict <model> <FASTA>`: same TSV.  And the `<fasta>.gz.npz` one-hot file that
     `preprocess_sequence` writes as an alternative input: same rows as the FASTA it was made from."""
@@ -687,6 +687,9 @@ def test_cli_console_forms_and_npz_input(tmp_path):
     entry("deepgrp")(["predict", mpath, npz, "--output", out3])
     rows = lambda p: [ln.split("\t")[2:] for ln in open(p).read().splitlines()]
     assert rows(out3) == rows(out2)
+    # ... and as the ORACLE's post-processing of the same probabilities gives them (not only the product's own FASTA run)
+    want = _expected_tsv(orc, str(fa), mpath, None, 50, 256, 50, 50, True)
+    assert [ln.split("\t")[2:] for ln in want.splitlines()] == rows(out3)
     assert {ln.split("\t")[1] for ln in open(out3).read().splitlines()} == {"one.fa.gz"}
 
 
