@@ -45,6 +45,10 @@ while time.time() < t_end:
     else:
         w = orc.Weights.random(u, nc, T, att, seed=int(rng.integers(0, 1 << 30)), gain=gain)
         m = DeviceModel(w.kernel, w.recurrent, w.bias, w.ff_kernel, w.ff_bias, w.scale, vecsize=T)
+    # lanes (attention models: chunks alternating between the library's internal streams) forced onto these small records now and then
+    os.environ.pop("DGRP_LANE_CHUNK", None)
+    if att and rng.integers(0, 3) == 0:
+        os.environ["DGRP_LANE_CHUNK"] = str(int(rng.choice([16, 32, 64, 256])))
     fast = bool(rng.integers(0, 2))                    # the fp16-operand kernel, or the default (split operands where they exist)
     pipe = ContigPipeline(m, s, B, ml, xd, use_mss=use_mss, fast=fast)
     m.set_precision(1 if pipe.split else 0)
