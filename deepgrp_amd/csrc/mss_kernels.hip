@@ -129,7 +129,7 @@ static mss_layout mss_carve(void *work, int64_t n)
     l.ustart2 = (int64_t *)take((2 * maxunits + 2) * 8);
     l.urun2 = (int64_t *)take((2 * maxunits + 2) * 8);
     l.entry2 = (double *)take((2 * maxunits + 2) * 8);
-    l.subs = take((3 * maxunits + 8) * (int64_t)MSS_SUBENT_BYTES);
+    l.subs = take((maxunits + 8) * (int64_t)MSS_SUBENT_BYTES);      // (the sub-piece scan is taken only with at most nblk units)
     l.dump_cap = 2 * (l.nblk / MSS_SUB_MIN + 2);
     l.dump = (mss_cand *)take(l.dump_cap * MSS_LCAP * (int64_t)sizeof(mss_cand));
     l.stack = (mss_cand *)take(maxruns * (int64_t)sizeof(mss_cand));
